@@ -1,0 +1,506 @@
+// rl_core.h -- the per-path arithmetic of the trace kernel: camera ray, primitive scan, hit
+// completion, material bounce, Russian roulette, CIE lookup and splat weights.
+//
+// This is the device code.  It is written against RlSceneView (flat 16-byte records) instead of the
+// reference's trait objects and is restructured for a 64-wide wave:
+//   * the scan carries only (distance, id) and completes position/normal/tangent for the single
+//     winning primitive afterwards (the reference builds a full Intersection per candidate,
+//     geometry.rs:242-259);
+//   * the sphere test drops the reference's factors of two (b = 2 d.co, disc = b^2 - 4c, t = -(−b±√disc)/2,
+//     geometry.rs:204-221) -- scaling by powers of two is exact in binary floating point, so
+//     q = (d.co)^2 - c, t = d.co -/+ sqrt(q) gives bit-identical distances with 5 fewer operations;
+//   * a hexagonal prism (geometry.rs:493-515: Compound<InfinitePrism, Compound<InfinitePrism,
+//     ThickPlane>>) is evaluated as its fixed tree over 8 half-space records.
+// Every value that feeds a branch or the result is computed with the reference's operation order
+// and no fused multiply-add (build with -ffp-contract=off), so a path takes the same branches here
+// as in any IEEE-754 restatement of the Rust source.
+//
+// The functions are RL_HD only so that tests/host_mirror can compile this same file with g++ and
+// compare it with the oracle without a GPU.  The product never runs them on the CPU.
+#pragma once
+#include "rl_math.h"
+#include "rl_rng.h"
+#include "rl_scene.h"
+
+struct RlF3 {
+    float x, y, z;
+};
+RL_HD RlF3 rl_f3(float x, float y, float z) {
+    RlF3 r;
+    r.x = x;
+    r.y = y;
+    r.z = z;
+    return r;
+}
+RL_HD RlF3 rl_add(RlF3 a, RlF3 b) { return rl_f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RL_HD RlF3 rl_sub(RlF3 a, RlF3 b) { return rl_f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RL_HD RlF3 rl_neg(RlF3 a) { return rl_f3(-a.x, -a.y, -a.z); }
+RL_HD RlF3 rl_mul(RlF3 a, float f) { return rl_f3(a.x * f, a.y * f, a.z * f); }
+RL_HD float rl_dot(RlF3 a, RlF3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                    // vector3.rs:35-37
+RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                                                // vector3.rs:27-33
+    return rl_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
+    const float m = sqrtf(rl_dot(v, v));
+    if (m == 0.0f) return v;
+    return rl_f3(v.x / m, v.y / m, v.z / m);
+}
+RL_HD RlF3 rl_reflect(RlF3 v, RlF3 n) { return rl_sub(v, rl_mul(rl_mul(n, 2.0f), rl_dot(n, v))); }   // vector3.rs:91-93
+RL_HD RlF3 rl_rotate_towards(RlF3 v, RlF3 n) {                                                       // vector3.rs:69-83
+    if (n.z > 0.9999f) return v;
+    if (n.z < -0.9999f) return rl_f3(v.x, v.y, -v.z);
+    const RlF3 a1 = rl_normalise(rl_cross(rl_f3(0.0f, 0.0f, 1.0f), n));
+    const RlF3 a2 = rl_normalise(rl_cross(a1, n));
+    return rl_add(rl_add(rl_mul(a1, v.x), rl_mul(a2, v.y)), rl_mul(n, v.z));
+}
+RL_HD RlF3 rl_xyz(RlF4 v) { return rl_f3(v.x, v.y, v.z); }
+
+struct RlQuat {
+    float x, y, z, w;
+};
+RL_HD RlQuat rl_qmul(RlQuat a, RlQuat b) {                                                           // quaternion.rs:100-111
+    RlQuat r;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+    r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    return r;
+}
+RL_HD RlF3 rl_qrotate(RlF3 v, RlQuat q) {                                                            // vector3.rs:85-89
+    RlQuat p;
+    p.x = v.x; p.y = v.y; p.z = v.z; p.w = 0.0f;
+    RlQuat c;
+    c.x = -q.x; c.y = -q.y; c.z = -q.z; c.w = q.w;
+    const RlQuat r = rl_qmul(rl_qmul(q, p), c);
+    return rl_f3(r.x, r.y, r.z);
+}
+
+// ---- state of one path ------------------------------------------------------------------------
+
+struct RlPath {
+    RlF3 origin, direction;  // ray.rs:19-33 (probability folded into `intensity`)
+    float wavelength;
+    float intensity;         // trace_unit.rs:88
+    float continue_chance;   // trace_unit.rs:84
+    float sx, sy;            // screen position, trace_unit.rs:157-158
+    uint32_t bounce;         // RNG block = 2 + bounce
+};
+
+enum { RL_HIT_NONE = 0xffffffffu };
+
+struct RlHit {
+    float t;
+    uint32_t obj; // object index or RL_HIT_NONE
+    uint32_t sub; // prism: which of the 8 half-spaces
+};
+
+// ---- camera: trace_unit.rs:151-148, app.rs:327-357, camera.rs:47-108 --------------------------
+
+RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t seed, uint32_t stream, uint64_t path,
+                         RlPath* p) {
+    const RlRngBlock b0 = rl_rng_block(seed, stream, path, 0);
+    const float wavelength = rl_get_wavelength(b0.w[0]);
+    const float x = rl_get_bi_unit(b0.w[1]);
+    const float y = rl_get_bi_unit(b0.w[2]) / aspect_ratio;
+    const float t = rl_get_unit(b0.w[3]);
+
+    // make_camera(t)
+    const RlCameraDesc& cd = sv.camera;
+    const float phi = RL_PI_F * (cd.phi0 + cd.phi1 * t);
+    const float alpha = RL_PI_F * (cd.alpha0 + cd.alpha1 * t);
+    const float distance = cd.dist0 + cd.dist1 * t;
+    float sin_a, cos_a, sin_p, cos_p;
+    rl_sincosf(alpha, &sin_a, &cos_a);
+    rl_sincosf(phi, &sin_p, &cos_p);
+    const RlF3 position = rl_f3(cos_a * sin_p * distance, cos_a * cos_p * distance, sin_a * distance);
+    float s1, c1, s2, c2;
+    rl_sincosf((phi + RL_PI_F) * 0.5f, &s1, &c1);
+    rl_sincosf((-alpha) * 0.5f, &s2, &c2);
+    RlQuat q1, q2;
+    q1.x = s1 * 0.0f; q1.y = s1 * 0.0f; q1.z = s1 * -1.0f; q1.w = c1;   // rotation(0, 0, -1, phi + PI)
+    q2.x = s2 * 1.0f; q2.y = s2 * 0.0f; q2.z = s2 * 0.0f;  q2.w = c2;   // rotation(1, 0, 0, -alpha)
+    const RlQuat orientation = rl_qmul(q1, q2);
+    const float focal_distance = distance * cd.focal_factor;
+
+    // Camera::get_ray
+    const RlRngBlock b1 = rl_rng_block(seed, stream, path, 1);
+    const float dof_angle = rl_get_longitude(b1.w[0]);
+    const float dof_radius = rl_get_unit(b1.w[1]) / cd.depth_of_field;
+    const float d = (wavelength - 580.0f) / 200.0f;
+    const float zoom = 1.0f + d * cd.chromatic_abberation;
+
+    // Camera::get_screen_ray
+    const float xs = x * zoom;
+    const float ys = y * zoom;
+    const RlF3 direction = rl_normalise(rl_f3(xs, sv.screen_distance, -ys));
+    const RlF3 focus_point = rl_mul(direction, focal_distance / direction.y);
+    float sin_d, cos_d;
+    rl_sincosf(dof_angle, &sin_d, &cos_d);
+    const RlF3 lens_point = rl_f3(cos_d * dof_radius, 0.0f, sin_d * dof_radius);
+
+    p->origin = rl_add(position, rl_qrotate(lens_point, orientation));
+    p->direction = rl_normalise(rl_qrotate(rl_sub(focus_point, lens_point), orientation));
+    p->wavelength = wavelength;
+    p->intensity = 1.0f;
+    p->continue_chance = 1.0f;
+    p->sx = x;
+    p->sy = y;
+    p->bounce = 0;
+}
+
+// ---- the scan: scene.rs:39-60 over the flat records --------------------------------------------
+
+// geometry.rs:55-71 without the position.  Returns t > 0 or a negative number for "no hit".
+RL_HD float rl_plane_t(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* dn_out) {
+    const RlF3 lo = rl_sub(o, off);
+    const float dn = rl_dot(n, dir);
+    *dn_out = dn;
+    if (dn == 0.0f) return -1.0f;
+    const float t = -rl_dot(n, lo) / dn;
+    if (t <= 0.0f) return -1.0f;
+    return t;
+}
+// geometry.rs:123-127
+RL_HD bool rl_inside(RlF3 n, RlF3 off, RlF3 p) { return rl_dot(rl_sub(p, off), n) < 0.0f; }
+
+// geometry.rs:298-341: the distance only.
+RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir) {
+    const RlF3 origin = rl_sub(o, offset);
+    const RlF3 focal_offset = rl_sub(origin, focal_point);
+    const float n_dot_d = rl_dot(normal, dir);
+    const float n_dot_o = rl_dot(normal, origin);
+    const float d_dot_f = rl_dot(dir, focal_offset);
+    const float a = n_dot_d * n_dot_d - 1.0f;
+    const float b = 2.0f * n_dot_d * n_dot_o - 2.0f * d_dot_f;
+    const float c = n_dot_o * n_dot_o - rl_dot(focal_offset, focal_offset);
+    if (a == 0.0f) {
+        const float t1 = -c / b;
+        if (t1 < 0.0f) return -1.0f;
+        return t1; // may be +0 or NaN exactly as in the reference
+    }
+    const float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f) return -1.0f;
+    const float sq = sqrtf(disc);
+    const float p = 0.5f * (-b + sq) / a;
+    const float q = 0.5f * (-b - sq) / a;
+    if (p > 0.0f && (p < q || q < 0.0f)) return p;
+    if (q > 0.0f) return q;
+    return -1.0f;
+}
+
+// One candidate of a Compound: distance and which half-space, t < 0 = None.
+struct RlCand {
+    float t;
+    uint32_t k;
+};
+
+// Compound::intersect's selection (geometry.rs:386-399) given both children's (already filtered)
+// candidates: nearest wins, tie -> second child.
+RL_HD RlCand rl_compound_pick(RlCand a, RlCand b) {
+    if (a.t >= 0.0f && b.t >= 0.0f) return (a.t < b.t) ? a : b;
+    return (a.t >= 0.0f) ? a : b;
+}
+
+// HexagonalPrism = Compound<InfinitePrism[0,1,2], Compound<InfinitePrism[3,4,5], ThickPlane[6,7]>>
+// with InfinitePrism[a,b,c] = Compound<Compound<a,b>,c> (geometry.rs:409-416).  pr points at the
+// prism's 16 records.
+RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
+    RlF3 n[8], off[8];
+    float t[8];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; ++k) {
+        n[k] = rl_xyz(pr[2 * k]);
+        off[k] = rl_xyz(pr[2 * k + 1]);
+        float dn;
+        t[k] = rl_plane_t(n[k], off[k], o, dir, &dn);
+    }
+    // A candidate of half-space k survives a filter against the set `mask` when its position lies
+    // inside every half-space of the set.
+    auto filt = [&](RlCand c, uint32_t mask) -> RlCand {
+        if (c.t < 0.0f) return c;
+        const RlF3 pos = rl_add(o, rl_mul(dir, c.t));
+        bool in = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 8; ++j)
+            if (mask & (1u << j)) in = in && rl_inside(n[j], off[j], pos);
+        if (!in) c.t = -1.0f;
+        return c;
+    };
+    auto leaf = [&](int k) -> RlCand {
+        RlCand c;
+        c.t = t[k];
+        c.k = (uint32_t)k;
+        return c;
+    };
+    auto inf_prism = [&](int a, int b, int c) -> RlCand {
+        const RlCand ab = rl_compound_pick(filt(leaf(a), 1u << b), filt(leaf(b), 1u << a));
+        return rl_compound_pick(filt(ab, 1u << c), filt(leaf(c), (1u << a) | (1u << b)));
+    };
+    const RlCand ip_bevel = inf_prism(0, 1, 2);
+    const RlCand ip_main = inf_prism(3, 4, 5);
+    const RlCand thick = rl_compound_pick(filt(leaf(6), 1u << 7), filt(leaf(7), 1u << 6));
+    const RlCand prism = rl_compound_pick(filt(ip_main, 0xC0u), filt(thick, 0x38u));
+    return rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
+}
+
+RL_HD bool rl_nearer(float t, uint32_t obj, const RlHit& best) {
+    return t < best.t || (t == best.t && obj < best.obj);
+}
+
+RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
+    RlHit best;
+    best.t = 1.0e12f; // scene.rs:43
+    best.obj = RL_HIT_NONE;
+    best.sub = 0;
+
+    // Spheres (geometry.rs:204-240).  `slot` is translated to the object index after the loop.
+    uint32_t slot = RL_HIT_NONE;
+    for (uint32_t i = 0; i < sv.n_spheres; ++i) {
+        const RlF4 s = sv.spheres[i];
+        const float cox = s.x - o.x, coy = s.y - o.y, coz = s.z - o.z;
+        const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
+        const float c = (cox * cox + coy * coy + coz * coz) - s.w;
+        const float q = dd * dd - c;
+        if (q >= 0.0f && dd > 0.0f) {
+            const float sq = sqrtf(q);
+            const float t1 = dd - sq;
+            const float t2 = dd + sq;
+            if (t1 > 0.0f && t1 < t2 && t1 < best.t) {
+                best.t = t1;
+                slot = i;
+            }
+        }
+    }
+    if (slot != RL_HIT_NONE) best.obj = sv.sphere_obj[slot];
+
+    // Paraboloids.
+    for (uint32_t i = 0; i < sv.n_parabs; ++i) {
+        const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
+        const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
+        const uint32_t obj = rl_f2u(r0.w);
+        if (!(t < 0.0f) && rl_nearer(t, obj, best)) {
+            best.t = t;
+            best.obj = obj;
+        }
+    }
+    // Planes and circles.
+    for (uint32_t i = 0; i < sv.n_planes; ++i) {
+        const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];
+        float dn;
+        const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
+        bool hit = t > 0.0f;
+        if (hit && r0.w >= 0.0f) { // circle: geometry.rs:168-171
+            const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
+            hit = rl_dot(dp, dp) <= r0.w;
+        }
+        const uint32_t obj = rl_f2u(r1.w);
+        if (hit && rl_nearer(t, obj, best)) {
+            best.t = t;
+            best.obj = obj;
+        }
+    }
+    // Hexagonal prisms.
+    for (uint32_t i = 0; i < sv.n_prisms; ++i) {
+        const RlF4* pr = sv.prisms + 16 * i;
+        const RlCand c = rl_hex_prism(pr, o, dir);
+        const uint32_t obj = rl_f2u(pr[1].w);
+        if (c.t >= 0.0f && rl_nearer(c.t, obj, best)) {
+            best.t = c.t;
+            best.obj = obj;
+            best.sub = c.k;
+        }
+    }
+    return best;
+}
+
+// ---- hit completion (geometry.rs:73-86,110-121,166-184,242-259,343-357) -------------------------
+
+struct RlIsect {
+    RlF3 position, normal, tangent;
+};
+
+RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit& hit, uint32_t surface_kind,
+                            uint32_t group_index) {
+    RlIsect is;
+    is.position = rl_add(o, rl_mul(dir, hit.t));
+    is.tangent = rl_f3(0.0f, 0.0f, 0.0f);
+    if (surface_kind == RL_SURFACE_SPHERE) {
+        const RlF4 s = sv.spheres[group_index];
+        is.normal = rl_normalise(rl_sub(is.position, rl_xyz(s)));
+        is.tangent = rl_normalise(rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal));
+    } else if (surface_kind == RL_SURFACE_PARABOLOID) {
+        const RlF3 offset = rl_xyz(sv.parabs[3 * group_index]);
+        const RlF3 normal = rl_xyz(sv.parabs[3 * group_index + 1]);
+        const RlF3 focal_point = rl_xyz(sv.parabs[3 * group_index + 2]);
+        const RlF3 local_pos = rl_sub(is.position, offset);
+        const RlF3 plane_pr = rl_sub(local_pos, rl_mul(normal, rl_dot(local_pos, normal)));
+        is.normal = rl_normalise(rl_sub(focal_point, plane_pr));
+    } else if (surface_kind == RL_SURFACE_HEX_PRISM) {
+        is.normal = rl_xyz(sv.prisms[16 * group_index + 2 * hit.sub]); // SpacePartitioning: one-sided
+    } else { // plane, circle: two-sided
+        const RlF3 n = rl_xyz(sv.planes[2 * group_index]);
+        is.normal = (rl_dot(n, dir) < 0.0f) ? n : rl_neg(n);
+    }
+    return is;
+}
+
+// ---- materials (material.rs) -------------------------------------------------------------------
+
+// material.rs:61-74
+RL_HD double rl_boltzmann(double wavelength, double temperature) {
+    const double h = 6.62606957e-34, k = 1.3806488e-23, c = 299792458.0; // constants.rs:19-23
+    const double f = c / (wavelength * 1.0e-9);
+    return (2.0 * h * f * f * f) / (c * c * (rl_exp_d(h * f / (k * temperature)) - 1.0));
+}
+// material.rs:93-99
+RL_HD float rl_black_body_normalisation(float kelvins, float intensity) {
+    const double wien = 2.897772126e-3; // constants.rs:25
+    return intensity / (float)rl_boltzmann((wien / (double)kelvins) * 1.0e9, (double)kelvins);
+}
+// material.rs:203-213
+RL_HD float rl_sf10_ior(float wavelength) {
+    const double w2 = (double)(wavelength * wavelength * 1.0e-6f);
+    return (float)sqrt(1.0 + 1.737596950 * w2 / (w2 - 0.0131887070) + 0.313747346 * w2 / (w2 - 0.0623068142) +
+                       1.898781010 * w2 / (w2 - 155.23629000));
+}
+RL_HD float rl_clamp999(float x) { // material.rs:288-292
+    if (x < -0.999f) return -0.999f;
+    if (x > 0.999f) return 0.999f;
+    return x;
+}
+
+// One step of TraceUnit::render_ray's loop body after the scan (trace_unit.rs:92-126).
+// Returns true when the path ended; *value is then its contribution (trace_unit.rs:94,100,131).
+RL_HD bool rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint64_t path_index, RlPath* p,
+                     const RlHit& hit, float* value) {
+    if (hit.obj == RL_HIT_NONE) { // The Void
+        *value = 0.0f;
+        return true;
+    }
+    const RlF4 oa = sv.objects[2 * hit.obj];
+    const RlF4 ob = sv.objects[2 * hit.obj + 1];
+    const uint32_t kinds = rl_f2u(oa.x);
+    const uint32_t surface_kind = kinds & 0xffu;
+    const uint32_t material_kind = kinds >> 8;
+    if (material_kind == RL_MATERIAL_BLACK_BODY) { // material.rs:101-105
+        *value = p->intensity * ((float)rl_boltzmann((double)p->wavelength, (double)ob.x) * ob.y);
+        return true;
+    }
+    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y));
+    const RlRngBlock rb = rl_rng_block(seed, stream, path_index, 2u + p->bounce);
+    const RlF3 in_dir = p->direction;
+    RlF3 new_dir;
+    float probability;
+
+    if (material_kind == RL_MATERIAL_SF10_GLASS) { // material.rs:216-260
+        float cos_i = -rl_dot(in_dir, is.normal);
+        float ior = rl_sf10_ior(p->wavelength);
+        RlF3 normal = is.normal;
+        if (cos_i > 0.0f) {
+            ior = 1.0f / ior;
+        } else {
+            normal = rl_neg(normal);
+            cos_i = -cos_i;
+        }
+        const float sin_t_sqr = ior * ior * (1.0f - cos_i * cos_i);
+        if (sin_t_sqr > 1.0f) {
+            new_dir = rl_reflect(in_dir, normal);
+        } else {
+            const float cos_t = sqrtf(1.0f - sin_t_sqr);
+            new_dir = rl_add(rl_mul(in_dir, ior), rl_mul(normal, ior * cos_i - cos_t));
+        }
+        probability = 1.0f;
+    } else if (material_kind == RL_MATERIAL_SOAP_BUBBLE) { // material.rs:267-305
+        const float cos_alpha = rl_dot(in_dir, is.normal);
+        if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = rl_reflect(in_dir, is.normal);
+        else new_dir = in_dir;
+        const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
+        const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
+        const float cos_theta = rl_clamp999(rl_dot(new_dir, is.tangent));
+        const float pc = rl_cosf(phase_shift - rl_acosf(cos_phi) * 3.0f - rl_acosf(cos_theta) * 2.0f + RL_PI_F * 0.5f);
+        probability = pc * 0.1f + 0.9f;
+    } else { // the diffuse family: material.rs:38-58 then :122-130 / :155-168 / :185-196
+        const float phi = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58
+        const float rq = rl_get_unit(rb.w[1]);
+        const float r = sqrtf(rq);
+        float sin_p, cos_p;
+        rl_sincosf(phi, &sin_p, &cos_p);
+        const RlF3 hemi = rl_f3(cos_p * r, sin_p * r, sqrtf(1.0f - rq));
+        const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
+        new_dir = rl_rotate_towards(hemi, facing);
+        probability = 1.0f;
+        if (material_kind == RL_MATERIAL_DIFFUSE_GREY) {
+            probability = ob.x;
+        } else if (material_kind == RL_MATERIAL_DIFFUSE_COLOURED) {
+            const float pw = (ob.y - p->wavelength) / ob.z;
+            probability = ob.x * rl_expf(-0.5f * pw * pw);
+        } else { // glossy mirror: blends with the mirror direction about the un-flipped normal
+            const RlF3 reflection = rl_reflect(in_dir, is.normal);
+            new_dir = rl_normalise(rl_add(rl_mul(new_dir, ob.x), rl_mul(reflection, 1.0f - ob.x)));
+        }
+    }
+
+    p->intensity = p->intensity * probability;                         // trace_unit.rs:106
+    p->direction = new_dir;
+    p->origin = rl_add(is.position, rl_mul(new_dir, 0.00001f));        // trace_unit.rs:114
+    p->continue_chance = p->continue_chance * 0.96f;                   // trace_unit.rs:117
+    p->bounce += 1;
+    if (rl_get_unit(rb.w[2]) * 0.85f > p->continue_chance * (1.0f - rl_expf(p->intensity * -20.0f))) { // :122-125
+        *value = 0.0f;
+        return true;
+    }
+    return false;
+}
+
+// ---- cie1931.rs:20-48 and plot_unit.rs:56-84 ----------------------------------------------------
+
+RL_HD RlF3 rl_tristimulus(const RlF4* cie, float wavelength) {
+    const float indexf = (wavelength - 380.0f) / 5.0f;
+    const float fl = floorf(indexf);
+    const int index = (int)fl;
+    const float remainder = indexf - (float)index;
+    if (index < -1 || index > 80) return rl_f3(0.0f, 0.0f, 0.0f);
+    if (index == -1) {
+        const RlF4 a = cie[0];
+        return rl_f3(a.x * remainder, a.y * remainder, a.z * remainder);
+    }
+    if (index == 80) {
+        const RlF4 a = cie[80];
+        return rl_f3(a.x * (1.0f - remainder), a.y * (1.0f - remainder), a.z * (1.0f - remainder));
+    }
+    const RlF4 a = cie[index], b = cie[index + 1];
+    return rl_f3(a.x * (1.0f - remainder) + b.x * remainder, a.y * (1.0f - remainder) + b.y * remainder,
+                 a.z * (1.0f - remainder) + b.z * remainder);
+}
+
+struct RlSplat {
+    uint32_t idx[4]; // pixel indices in the reference's order: (py1,px1) (py1,px2) (py2,px1) (py2,px2)
+    float w[4];      // c11 c21 c12 c22
+};
+
+RL_HD RlSplat rl_splat_weights(uint32_t width, uint32_t height, float aspect_ratio, float x, float y) {
+    const int w = (int)width, h = (int)height;
+    const float px = (x * 0.5f + 0.5f) * ((float)w - 1.0f);
+    const float py = (y * aspect_ratio * 0.5f + 0.5f) * ((float)h - 1.0f);
+    int px1 = (int)floorf(px), px2 = (int)ceilf(px), py1 = (int)floorf(py), py2 = (int)ceilf(py);
+    px1 = px1 < 0 ? 0 : (px1 > w - 1 ? w - 1 : px1);
+    px2 = px2 < 0 ? 0 : (px2 > w - 1 ? w - 1 : px2);
+    py1 = py1 < 0 ? 0 : (py1 > h - 1 ? h - 1 : py1);
+    py2 = py2 < 0 ? 0 : (py2 > h - 1 ? h - 1 : py2);
+    const float cx = px - (float)px1;
+    const float cy = py - (float)py1;
+    RlSplat s;
+    s.w[0] = (1.0f - cx) * (1.0f - cy);
+    s.w[1] = cx * (1.0f - cy);
+    s.w[2] = (1.0f - cx) * cy;
+    s.w[3] = cx * cy;
+    s.idx[0] = (uint32_t)(py1 * w + px1);
+    s.idx[1] = (uint32_t)(py1 * w + px2);
+    s.idx[2] = (uint32_t)(py2 * w + px1);
+    s.idx[3] = (uint32_t)(py2 * w + px2);
+    return s;
+}

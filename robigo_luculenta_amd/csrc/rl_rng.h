@@ -1,0 +1,70 @@
+// rl_rng.h -- counter-based random numbers shared by the gfx950 kernels and the host code.
+//
+// The reference draws from rand 0.3.11's OS-seeded thread-local generator (monte_carlo.rs:22-38),
+// which cannot be seeded, so "matched seed" has to be defined by the build: every draw is a pure
+// function of (seed, stream, path_index, block, slot).  Philox4x32-10 (Salmon et al., SC'11) is the
+// generator; one call yields the four 32-bit slots of one block.
+//
+//   block 0        : slot 0 wavelength, slot 1 screen x, slot 2 screen y, slot 3 camera time
+//                    (trace_unit.rs:154-158,138)
+//   block 1        : slot 0 depth-of-field angle (half-open), slot 1 depth-of-field radius
+//                    (camera.rs:96-97)
+//   block 2 + b    : bounce b: slot 0 hemisphere longitude (half-open) or the soap-bubble
+//                    reflect/pass draw, slot 1 hemisphere radius^2, slot 2 Russian roulette
+//                    (monte_carlo.rs:48-49, material.rs:273, trace_unit.rs:122)
+//
+// Every lane of a wave therefore makes exactly one Philox call per bounce regardless of which
+// material it hit -- no divergence and no cached words live across the intersection scan.
+//
+// u32 -> f32 follows rand 0.3.11's conversions: [0,1) keeps the top 24 bits and scales by 2^-24;
+// Closed01 rescales that by 2^24/(2^24-1) so that 1.0 is reachable (monte_carlo.rs:25-28).
+#pragma once
+#include "rl_math.h"
+
+struct RlRngBlock {
+    uint32_t w[4];
+};
+
+RL_HD uint32_t rl_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int round = 0; round < 10; ++round) {
+        const uint32_t hi0 = rl_mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = rl_mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    RlRngBlock r;
+    r.w[0] = c0;
+    r.w[1] = c1;
+    r.w[2] = c2;
+    r.w[3] = c3;
+    return r;
+}
+
+// One block of draws for (seed, stream, path, block).
+RL_HD RlRngBlock rl_rng_block(uint64_t seed, uint32_t stream, uint64_t path, uint32_t block) {
+    return rl_philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, (uint32_t)seed,
+                            (uint32_t)(seed >> 32));
+}
+
+// rand 0.3.11 `random::<f32>()`: 24 random bits in [0, 1).
+RL_HD float rl_halfopen01(uint32_t u) { return (float)(u >> 8) * 5.9604644775390625e-8f; }
+// rand 0.3.11 `random::<Closed01<f32>>()`: [0, 1].
+RL_HD float rl_closed01(uint32_t u) { return rl_halfopen01(u) * (16777216.0f / 16777215.0f); }
+
+// monte_carlo.rs:25-43 on top of the draws.
+RL_HD float rl_get_unit(uint32_t u) { return rl_closed01(u); }
+RL_HD float rl_get_bi_unit(uint32_t u) { return rl_closed01(u) * 2.0f - 1.0f; }
+RL_HD float rl_get_longitude(uint32_t u) { return rl_halfopen01(u) * RL_PI_F * 2.0f; }
+RL_HD float rl_get_wavelength(uint32_t u) { return rl_closed01(u) * 400.0f + 380.0f; }

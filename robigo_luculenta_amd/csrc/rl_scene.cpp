@@ -1,0 +1,240 @@
+// rl_scene.cpp -- host side of the scene: the built-in generators and the flattening of an
+// RlSceneDesc into the 16-byte records of rl_scene.h.  Pure host code (no device needed).
+#include "rl_scene.h"
+
+#include <cstring>
+
+#include "rl_core.h"
+
+namespace {
+
+const float PI = RL_PI_F;
+
+RlVector3 V(float x, float y, float z) {
+    RlVector3 v;
+    v.x = x; v.y = y; v.z = z;
+    return v;
+}
+RlVector3 V(RlF3 f) { return V(f.x, f.y, f.z); }
+RlF3 F(const RlVector3& v) { return rl_f3(v.x, v.y, v.z); }
+RlF4 F4(RlF3 v, float w) {
+    RlF4 r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = w;
+    return r;
+}
+
+RlObjectDesc make_object(uint32_t surface, RlVector3 v0, RlVector3 v1, float f0, float f1, float f2, float f3,
+                         uint32_t material, float m0, float m1, float m2) {
+    RlObjectDesc o;
+    std::memset(&o, 0, sizeof o);
+    o.surface_kind = surface;
+    o.material_kind = material;
+    o.v0 = v0; o.v1 = v1;
+    o.f0 = f0; o.f1 = f1; o.f2 = f2; o.f3 = f3;
+    o.m0 = m0; o.m1 = m1; o.m2 = m2;
+    return o;
+}
+RlObjectDesc sphere(RlF3 c, float r, uint32_t mat, float m0 = 0, float m1 = 0, float m2 = 0) {
+    return make_object(RL_SURFACE_SPHERE, V(c), V(0, 0, 0), r, 0, 0, 0, mat, m0, m1, m2);
+}
+
+// Paraboloid::new's derived fields (geometry.rs:286-295).
+struct ParabFields {
+    RlF3 offset, normal, focal_point;
+};
+ParabFields paraboloid_fields(RlF3 normal, RlF3 offset, float focal_distance) {
+    ParabFields p;
+    p.normal = normal;
+    p.offset = rl_sub(offset, rl_mul(normal, focal_distance));
+    p.focal_point = rl_mul(normal, focal_distance * 2.0f);
+    return p;
+}
+
+// The seven fixed objects of the demo scene: sun, floor, two walls, two sky lights, ceiling
+// (app.rs:171-231).
+void push_fixed_objects(std::vector<RlObjectDesc>& out, float sun_radius) {
+    const float r2 = sun_radius * sun_radius; // sun_radius.powi(2)
+    const float sky_height = 30.0f;
+    const RlVector3 down = V(0, 0, -1.0f), up = V(0, 0, 1.0f);
+    out.push_back(sphere(rl_f3(0, 0, 0), sun_radius, RL_MATERIAL_BLACK_BODY, 6504.0f, 1.0f));
+    out.push_back(make_object(RL_SURFACE_PARABOLOID, down, V(0, 0, -sun_radius), r2, 0, 0, 0, RL_MATERIAL_DIFFUSE_GREY, 0.8f, 0, 0));
+    out.push_back(make_object(RL_SURFACE_PARABOLOID, up, V(1.0f, 0, -r2), r2, 0, 0, 0, RL_MATERIAL_DIFFUSE_COLOURED, 0.9f, 550.0f, 40.0f));
+    out.push_back(make_object(RL_SURFACE_PARABOLOID, up, V(-1.0f, 0, -r2), r2, 0, 0, 0, RL_MATERIAL_DIFFUSE_COLOURED, 0.9f, 660.0f, 60.0f));
+    out.push_back(make_object(RL_SURFACE_CIRCLE, down, V(-sun_radius, 0, sky_height), 5.0f, 0, 0, 0, RL_MATERIAL_BLACK_BODY, 7600.0f, 0.6f, 0));
+    out.push_back(make_object(RL_SURFACE_CIRCLE, down, V(-sun_radius * 0.5f, sun_radius * 2.0f + 15.0f, sky_height), 15.0f, 0,
+                              0, 0, RL_MATERIAL_BLACK_BODY, 5000.0f, 0.6f, 0));
+    out.push_back(make_object(RL_SURFACE_PLANE, down, V(0, 0, sky_height * 2.0f), 0, 0, 0, 0, RL_MATERIAL_DIFFUSE_COLOURED, 0.5f, 470.0f, 25.0f));
+}
+
+// A ring of `count` x 2 hexagonal SF10 prisms standing on the floor paraboloid (app.rs:287-325).
+void push_prism_ring(std::vector<RlObjectDesc>& out, float sun_radius, int count, float prism_radius) {
+    const ParabFields floor = paraboloid_fields(rl_f3(0, 0, -1.0f), rl_f3(0, 0, -sun_radius), sun_radius * sun_radius);
+    const float prism_angle = PI * 2.0f / (float)count;
+    const float prism_height = 8.0f;
+    const float variants[2][4] = {{0.0f, 1.0f, 0.0f, 1.0f}, {0.5f * prism_angle, 1.2f, PI * 0.5f, 1.5f}};
+    for (int i = 0; i < count; ++i) {
+        for (int v = 0; v < 2; ++v) {
+            const float ofs = variants[v][0], radius = variants[v][1], phi_ofs = variants[v][2], h = variants[v][3];
+            const float phi = (float)i * prism_angle + ofs;
+            RlF3 position = rl_f3(rl_cosf(phi) * prism_radius * radius, rl_sinf(phi) * prism_radius * radius, 0.0f);
+            RlF3 normal = rl_f3(0, 0, -1.0f);
+            // Shoot straight down at the floor to find where the prism stands and how it leans.
+            const float t = rl_paraboloid_t(floor.offset, floor.normal, floor.focal_point, position, normal);
+            if (!(t < 0.0f)) {
+                const RlF3 pos = rl_add(position, rl_mul(normal, t));
+                const RlF3 local_pos = rl_sub(pos, floor.offset);
+                const RlF3 plane_pr = rl_sub(local_pos, rl_mul(floor.normal, rl_dot(local_pos, floor.normal)));
+                const RlF3 surface_normal = rl_normalise(rl_sub(floor.focal_point, plane_pr));
+                normal = rl_neg(surface_normal);
+                position = rl_add(pos, rl_mul(rl_mul(normal, 2.0f), h));
+            }
+            out.push_back(make_object(RL_SURFACE_HEX_PRISM, V(normal), V(position), 3.0f, 1.0f, phi + phi_ofs, prism_height * h,
+                                      RL_MATERIAL_SF10_GLASS, 0, 0, 0));
+        }
+    }
+}
+
+RlCameraDesc demo_camera() { // app.rs:327-357
+    RlCameraDesc c;
+    c.phi0 = 1.0f; c.phi1 = 0.01f;
+    c.alpha0 = 0.3f; c.alpha1 = -0.01f;
+    c.dist0 = 50.0f; c.dist1 = -0.5f;
+    c.fov_over_pi = 0.35f;
+    c.focal_factor = 0.9f;
+    c.depth_of_field = 2.0f;
+    c.chromatic_abberation = 0.012f;
+    return c;
+}
+
+// App::set_up_scene (app.rs:166-325) with `seeds` sunflower seeds per spiral.
+void demo_scene(int seeds, std::vector<RlObjectDesc>& out) {
+    const float sun_radius = 5.0f;
+    push_fixed_objects(out, sun_radius);
+    const double golden_ratio = 1.6180339887498948482045868343656381177203091798057628; // constants.rs:17
+    const float gamma = PI * 2.0f * (1.0f - 1.0f / (float)golden_ratio);
+    const float seed_size = 0.8f, seed_scale = 1.5f;
+    const float fs = sun_radius / seed_scale + 1.0f;
+    const int first_seed = (int)(fs * fs + 0.5f);
+    for (int i = first_seed; i < first_seed + seeds; ++i) { // app.rs:239-253
+        const float phi = (float)i * gamma;
+        const float r = sqrtf((float)i) * seed_scale;
+        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.5f), rl_f3(0, 0, 0));
+        out.push_back(sphere(c, seed_size, RL_MATERIAL_DIFFUSE_COLOURED, 0.9f,
+                             (float)(i - first_seed) / (float)seeds * 130.0f + 600.0f, 60.0f));
+    }
+    for (int i = first_seed; i < first_seed + seeds; ++i) { // app.rs:256-268
+        const float fi = (float)i + 0.5f;
+        const float phi = fi * gamma;
+        const float r = sqrtf(fi) * seed_scale;
+        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.25f), rl_f3(0, 0, 0));
+        out.push_back(sphere(c, seed_size * 0.5f, RL_MATERIAL_GLOSSY_MIRROR, 0.1f));
+    }
+    for (int i = first_seed / 2; i < first_seed + seeds; ++i) { // app.rs:271-284
+        const float phi = (float)(-i) * gamma;
+        const float root = sqrtf((float)i);
+        const float r = root * seed_scale * 1.5f;
+        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * 1.5f + sun_radius * 2.0f), rl_f3(0, 0, 0));
+        out.push_back(sphere(c, seed_size * (0.5f + root * 0.2f), RL_MATERIAL_SOAP_BUBBLE));
+    }
+    push_prism_ring(out, sun_radius, 11, 17.0f);
+}
+
+// BASELINE config 3: the seven fixed objects plus three rings of SF10 prisms at radius 10/17/24
+// built by the recipe of app.rs:287-325 (66 prisms, 528 half-spaces).  Not in the reference.
+void glass_stress_scene(std::vector<RlObjectDesc>& out) {
+    const float sun_radius = 5.0f;
+    push_fixed_objects(out, sun_radius);
+    push_prism_ring(out, sun_radius, 11, 10.0f);
+    push_prism_ring(out, sun_radius, 11, 17.0f);
+    push_prism_ring(out, sun_radius, 11, 24.0f);
+}
+
+// new_infinite_prism (geometry.rs:421-450): appends 3 half-spaces as {normal,0},{offset,obj}.
+void push_infinite_prism(std::vector<RlF4>& recs, RlF3 axis, RlF3 offset, float edge_length, float angle, float objbits) {
+    const float radius = sqrtf(3.0f) / 6.0f * edge_length;
+    const float a[3] = {angle, angle + PI * 2.0f / 3.0f, angle + PI * 4.0f / 3.0f};
+    for (int k = 0; k < 3; ++k) {
+        const RlF3 p = rl_rotate_towards(rl_f3(rl_cosf(a[k]), rl_sinf(a[k]), 0.0f), axis);
+        recs.push_back(F4(p, 0.0f));
+        recs.push_back(F4(rl_add(rl_mul(p, radius), offset), objbits));
+    }
+}
+
+} // namespace
+
+uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, RlCameraDesc* camera) {
+    std::vector<RlObjectDesc> objs;
+    if (which == RL_SCENE_DEMO) demo_scene(param > 0 ? param : 100, objs);
+    else if (which == RL_SCENE_GLASS_STRESS) glass_stress_scene(objs);
+    else return 0;
+    if (camera) *camera = demo_camera();
+    if (out) *out = objs;
+    return (uint32_t)objs.size();
+}
+
+int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err) {
+    *err = "";
+    if (!desc || (!desc->objects && desc->n_objects)) {
+        *err = "null scene description";
+        return RL_E_INVALID;
+    }
+    RlFlatScene& fs = *out;
+    fs = RlFlatScene();
+    fs.camera = desc->camera;
+    const float fov = PI * desc->camera.fov_over_pi;
+    fs.screen_distance = 1.0f / rl_tanf(fov * 0.5f); // camera.rs:56
+    for (uint32_t i = 0; i < desc->n_objects; ++i) {
+        const RlObjectDesc& o = desc->objects[i];
+        const float objbits = rl_u2f(i);
+        uint32_t group_index = 0;
+        switch (o.surface_kind) {
+        case RL_SURFACE_SPHERE:
+            group_index = (uint32_t)fs.spheres.size();
+            fs.spheres.push_back(F4(F(o.v0), o.f0 * o.f0)); // geometry.rs:195-200
+            fs.sphere_obj.push_back(i);
+            break;
+        case RL_SURFACE_PLANE:
+        case RL_SURFACE_CIRCLE:
+            group_index = (uint32_t)(fs.planes.size() / 2);
+            fs.planes.push_back(F4(F(o.v0), o.surface_kind == RL_SURFACE_CIRCLE ? o.f0 * o.f0 : -1.0f));
+            fs.planes.push_back(F4(F(o.v1), objbits));
+            break;
+        case RL_SURFACE_PARABOLOID: {
+            group_index = (uint32_t)(fs.parabs.size() / 3);
+            const ParabFields p = paraboloid_fields(F(o.v0), F(o.v1), o.f0);
+            fs.parabs.push_back(F4(p.offset, objbits));
+            fs.parabs.push_back(F4(p.normal, 0.0f));
+            fs.parabs.push_back(F4(p.focal_point, 0.0f));
+            break;
+        }
+        case RL_SURFACE_HEX_PRISM: { // geometry.rs:493-515
+            group_index = (uint32_t)(fs.prisms.size() / 16);
+            const RlF3 axis = F(o.v0), offset = F(o.v1);
+            const float edge_length = o.f0, bevel_size = o.f1, angle = o.f2, height = o.f3;
+            push_infinite_prism(fs.prisms, axis, offset, edge_length * 2.0f - bevel_size * 3.0f, angle + PI, objbits);
+            push_infinite_prism(fs.prisms, axis, offset, edge_length, angle, objbits);
+            fs.prisms.push_back(F4(rl_neg(axis), 0.0f)); // new_thick_plane, geometry.rs:455-468
+            fs.prisms.push_back(F4(offset, objbits));
+            fs.prisms.push_back(F4(axis, 0.0f));
+            fs.prisms.push_back(F4(rl_add(offset, rl_mul(axis, height)), objbits));
+            break;
+        }
+        default:
+            *err = "unknown surface kind";
+            return RL_E_INVALID;
+        }
+        RlF4 a, b;
+        a.x = rl_u2f((o.surface_kind & 0xffu) | (o.material_kind << 8));
+        a.y = rl_u2f(group_index);
+        a.z = 0.0f; a.w = 0.0f;
+        b.x = o.m0; b.y = o.m1; b.z = o.m2; b.w = 0.0f;
+        if (o.material_kind == RL_MATERIAL_BLACK_BODY) b.y = rl_black_body_normalisation(o.m0, o.m1);
+        else if (o.material_kind > RL_MATERIAL_SOAP_BUBBLE) {
+            *err = "unknown material kind";
+            return RL_E_INVALID;
+        }
+        fs.objects.push_back(a);
+        fs.objects.push_back(b);
+    }
+    return RL_OK;
+}

@@ -1,0 +1,63 @@
+"""ctypes view of tests/host_mirror (the kernel's per-path header compiled with g++).  Test-only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import _oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "host_mirror", "_build", "librl_mirror.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-s", "-C", os.path.join(HERE, "host_mirror")], check=True)
+        L = C.CDLL(SO)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.mirror_scene_create.restype = vp
+        L.mirror_scene_create.argtypes = [vp, u32, vp]
+        L.mirror_scene_destroy.argtypes = [vp]
+        L.mirror_builtin_desc.restype = u32
+        L.mirror_builtin_desc.argtypes = [C.c_int, C.c_int, vp, u32, vp]
+        L.mirror_render.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp, vp]
+        L.mirror_plot.argtypes = [vp, u32, u32, vp, u64]
+        _lib = L
+    return _lib
+
+
+def builtin_desc(which, param=0):
+    cam = O.RlCameraDesc()
+    n = lib().mirror_builtin_desc(which, param, None, 0, C.byref(cam))
+    objs = np.zeros(n, dtype=O.OBJECT_DTYPE)
+    lib().mirror_builtin_desc(which, param, O.ptr(objs), n, C.byref(cam))
+    return objs, cam
+
+
+class Scene:
+    def __init__(self, objs, cam):
+        self.objs = np.ascontiguousarray(objs)
+        self.h = lib().mirror_scene_create(O.ptr(self.objs), len(self.objs), C.byref(cam))
+        assert self.h
+
+    def __del__(self):
+        try:
+            lib().mirror_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def render(self, w, h, seed, stream, first, n):
+        photons = np.zeros(n, dtype=O.PHOTON_DTYPE)
+        segs = C.c_uint64(0)
+        lib().mirror_render(self.h, w, h, seed, stream, first, n, O.ptr(photons), C.byref(segs))
+        return photons, segs.value
+
+
+def plot(w, h, photons):
+    buffer = np.zeros((h * w, 3), dtype=np.float32)
+    photons = np.ascontiguousarray(photons)
+    lib().mirror_plot(O.ptr(buffer), w, h, O.ptr(photons), len(photons))
+    return buffer

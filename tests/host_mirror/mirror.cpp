@@ -1,0 +1,94 @@
+// mirror.cpp -- TEST INFRASTRUCTURE: compiles the kernel's per-path code (csrc/rl_core.h) with g++
+// so the flattened device arithmetic can be compared bit-for-bit with the oracle on a machine
+// without a GPU.  Never loaded by the product; the product's compute entry points run only the
+// hipcc build of the same header.
+#include <cstring>
+#include <vector>
+
+#include "../../robigo_luculenta_amd/csrc/rl_cie1931.h"
+#include "../../robigo_luculenta_amd/csrc/rl_core.h"
+#include "../../robigo_luculenta_amd/csrc/rl_scene.h"
+
+struct MirrorScene {
+    RlFlatScene flat;
+    RlSceneView view;
+};
+
+extern "C" {
+
+void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDesc* cam) {
+    RlSceneDesc d;
+    d.n_objects = n;
+    d.objects = objs;
+    d.camera = *cam;
+    MirrorScene* m = new MirrorScene();
+    const char* err;
+    if (rl_flatten_scene(&d, &m->flat, &err) != 0) {
+        delete m;
+        return nullptr;
+    }
+    RlSceneView& v = m->view;
+    v.spheres = m->flat.spheres.data();
+    v.planes = m->flat.planes.data();
+    v.parabs = m->flat.parabs.data();
+    v.prisms = m->flat.prisms.data();
+    v.objects = m->flat.objects.data();
+    v.sphere_obj = m->flat.sphere_obj.data();
+    v.cie = (const RlF4*)RL_CIE1931_XYZ0;
+    v.n_spheres = (uint32_t)m->flat.spheres.size();
+    v.n_planes = (uint32_t)(m->flat.planes.size() / 2);
+    v.n_parabs = (uint32_t)(m->flat.parabs.size() / 3);
+    v.n_prisms = (uint32_t)(m->flat.prisms.size() / 16);
+    v.n_objects = (uint32_t)(m->flat.objects.size() / 2);
+    v.camera = m->flat.camera;
+    v.screen_distance = m->flat.screen_distance;
+    return m;
+}
+void mirror_scene_destroy(void* s) { delete (MirrorScene*)s; }
+
+uint32_t mirror_builtin_desc(int which, int param, RlObjectDesc* out, uint32_t cap, RlCameraDesc* cam) {
+    std::vector<RlObjectDesc> v;
+    uint32_t n = rl_builtin_scene(which, param, &v, cam);
+    if (out && cap >= n) memcpy(out, v.data(), n * sizeof(RlObjectDesc));
+    return n;
+}
+
+void mirror_render(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first, uint64_t n,
+                   RlMappedPhoton* photons, uint64_t* segments) {
+    const RlSceneView& sv = ((MirrorScene*)scene)->view;
+    const float aspect = (float)w / (float)h;
+    uint64_t segs = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        RlPath p;
+        rl_begin_path(sv, aspect, seed, stream, first + i, &p);
+        float value = 0.0f;
+        for (;;) {
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            segs += 1;
+            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value)) break;
+        }
+        photons[i].x = p.sx;
+        photons[i].y = p.sy;
+        photons[i].probability = value;
+        photons[i].wavelength = p.wavelength;
+    }
+    if (segments) *segments = segs;
+}
+
+// plot_unit.rs:87-95 through the kernel's lookup + weights, sequential adds.
+void mirror_plot(RlVector3* buffer, uint32_t w, uint32_t h, const RlMappedPhoton* photons, uint64_t n) {
+    const float aspect = (float)w / (float)h;
+    const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const RlF3 t = rl_tristimulus(cie, photons[i].wavelength);
+        const RlF3 c = rl_mul(t, photons[i].probability);
+        const RlSplat s = rl_splat_weights(w, h, aspect, photons[i].x, photons[i].y);
+        for (int k = 0; k < 4; ++k) {
+            RlVector3& b = buffer[s.idx[k]];
+            b.x = b.x + c.x * s.w[k];
+            b.y = b.y + c.y * s.w[k];
+            b.z = b.z + c.z * s.w[k];
+        }
+    }
+}
+}
