@@ -232,6 +232,14 @@ int rl_scheduler_get_new_task(RlScheduler* s, const RlTask* completed, int64_t n
  * (task_scheduler.rs:308-325). */
 int rl_scheduler_performance(RlScheduler* s, float* mean, float* stddev);
 
+/* ---- diagnostics -------------------------------------------------------------------------------- */
+
+/* Not a reference interface: evaluates the shared numerics header (csrc/rl_math.h) on the GPU so a
+ * test can check that the hipcc and g++ builds agree bit-for-bit.  fn: 0 sin, 1 cos, 2 tan, 3 exp,
+ * 4 ln, 5 acos, 6 SF10 index of refraction (material.rs:203-213), 7 sqrt, 8 x[i] / x[i+1 mod n],
+ * 9 x^(1/2.4) (srgb.rs:24). */
+int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
+
 #ifdef __cplusplus
 }
 #endif

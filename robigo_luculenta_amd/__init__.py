@@ -1,0 +1,262 @@
+"""robigo_luculenta_amd -- MI355X-native hot path of the spectral path tracer robigo-luculenta.
+
+A thin ctypes mirror of the reference's unit structs over the C ABI (include/robigo_luculenta.h).
+Class and method names follow the Rust sources: TraceUnit.render / PlotUnit.plot, clear /
+GatherUnit.accumulate, save / TonemapUnit.tonemap / TaskScheduler.get_new_task.  All arithmetic
+runs in hand-written gfx950 kernels; numpy is used only to hold downloaded buffers."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (RlCameraDesc, RlError, RlMappedPhoton, RlObjectDesc, RlSceneDesc, RlTask, RlVector3, check, lib,
+                   RL_TASK_MAX_UNITS)
+
+PHOTON_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("probability", "<f4"), ("wavelength", "<f4")])
+OBJECT_DTYPE = np.dtype([("surface_kind", "<u4"), ("material_kind", "<u4"), ("v0", "<f4", 3), ("v1", "<f4", 3),
+                         ("f", "<f4", 4), ("m", "<f4", 3)])
+NUMBER_OF_PHOTONS = 1024 * 512  # trace_unit.rs:67
+
+SCENE_DEMO, SCENE_GLASS_STRESS = 0, 1
+FETCH_LDS, FETCH_GLOBAL = 0, 1
+TASK_SLEEP, TASK_TRACE, TASK_PLOT, TASK_GATHER, TASK_TONEMAP = range(5)
+
+
+def device_count():
+    return lib.rl_device_count()
+
+
+def version():
+    return lib.rl_version().decode()
+
+
+def builtin_scene_desc(which=SCENE_DEMO, param=0):
+    """Object array (OBJECT_DTYPE) and camera of a built-in scene (app.rs:166-363)."""
+    n = C.c_uint32(0)
+    cam = RlCameraDesc()
+    lib.rl_scene_builtin_desc(which, param, None, 0, C.byref(n), C.byref(cam))
+    if n.value == 0:
+        raise RlError(-1, "unknown built-in scene %r" % (which,))
+    objs = np.zeros(n.value, dtype=OBJECT_DTYPE)
+    check(lib.rl_scene_builtin_desc(which, param, objs.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(cam)))
+    return objs, cam
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            type(self)._destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene(_Handle):
+    """scene.rs:23-35; immutable after creation."""
+    _destroy = lib.rl_scene_destroy
+
+    def __init__(self, objects, camera, device=0):
+        super().__init__()
+        self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        desc = RlSceneDesc(len(self.objects), self.objects.ctypes.data_as(C.c_void_p), camera)
+        check(lib.rl_scene_create(C.byref(desc), device, C.byref(self._h)))
+        self.device = device
+
+    @classmethod
+    def builtin(cls, which=SCENE_DEMO, param=0, device=0):
+        objs, cam = builtin_scene_desc(which, param)
+        return cls(objs, cam, device)
+
+
+class TraceUnit(_Handle):
+    """trace_unit.rs:51-168."""
+    _destroy = lib.rl_trace_unit_destroy
+
+    def __init__(self, id, width, height, n_photons=NUMBER_OF_PHOTONS, device=0):
+        super().__init__()
+        check(lib.rl_trace_unit_create(device, id, width, height, n_photons, C.byref(self._h)))
+        self.id, self.width, self.height, self.n_photons, self.device = id, width, height, n_photons, device
+
+    def set_fetch(self, fetch):
+        check(lib.rl_trace_unit_set_fetch(self._h, fetch))
+
+    def render(self, scene, seed=1, stream=0, first_path_index=0):
+        check(lib.rl_trace_unit_render(self._h, scene.handle, seed, stream, first_path_index))
+
+    def render_fused(self, scene, plot_unit, n_paths, seed=1, stream=0, first_path_index=0):
+        check(lib.rl_trace_unit_render_fused(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index,
+                                             n_paths))
+
+    def sync(self):
+        check(lib.rl_trace_unit_sync(self._h))
+
+    @property
+    def mapped_photons(self):
+        out = np.zeros(self.n_photons, dtype=PHOTON_DTYPE)
+        check(lib.rl_trace_unit_photons(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def stats(self):
+        """(paths, segments, kernel_ms) accumulated since creation."""
+        p, s, ms = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        check(lib.rl_trace_unit_stats(self._h, C.byref(p), C.byref(s), C.byref(ms)))
+        return p.value, s.value, ms.value
+
+
+class PlotUnit(_Handle):
+    """plot_unit.rs:23-102."""
+    _destroy = lib.rl_plot_unit_destroy
+
+    def __init__(self, id, width, height, device=0, external_xyz=None):
+        super().__init__()
+        check(lib.rl_plot_unit_create(device, id, width, height, C.c_void_p(external_xyz or 0), C.byref(self._h)))
+        self.id, self.width, self.height, self.device = id, width, height, device
+
+    def plot(self, trace_units):
+        arr = (C.c_void_p * len(trace_units))(*[t.handle for t in trace_units])
+        check(lib.rl_plot_unit_plot(self._h, arr, len(trace_units)))
+
+    def clear(self):
+        check(lib.rl_plot_unit_clear(self._h))
+
+    def device_buffer(self):
+        p = C.c_void_p()
+        check(lib.rl_plot_unit_device_buffer(self._h, C.byref(p)))
+        return p.value
+
+    @property
+    def tristimulus_buffer(self):
+        out = np.zeros((self.height * self.width, 3), dtype=np.float32)
+        check(lib.rl_plot_unit_download(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+class GatherUnit(_Handle):
+    """gather_unit.rs:24-92 (resume is explicit: load())."""
+    _destroy = lib.rl_gather_unit_destroy
+
+    def __init__(self, width, height, device=0):
+        super().__init__()
+        check(lib.rl_gather_unit_create(device, width, height, C.byref(self._h)))
+        self.width, self.height, self.device = width, height, device
+
+    def accumulate(self, plot_unit):
+        """accumulate(&plot.tristimulus_buffer) then plot.clear() (app.rs:143-148)."""
+        check(lib.rl_gather_unit_accumulate(self._h, plot_unit.handle))
+
+    def save(self, path="buffer.raw"):
+        check(lib.rl_gather_unit_save(self._h, path.encode()))
+
+    def load(self, path="buffer.raw"):
+        check(lib.rl_gather_unit_load(self._h, path.encode()))
+
+    def _download(self):
+        t = np.zeros((self.height * self.width, 3), dtype=np.float32)
+        c = np.zeros_like(t)
+        check(lib.rl_gather_unit_download(self._h, t.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)))
+        return t, c
+
+    @property
+    def tristimulus_buffer(self):
+        return self._download()[0]
+
+    @property
+    def compensation_buffer(self):
+        return self._download()[1]
+
+
+class TonemapUnit(_Handle):
+    """tonemap_unit.rs:21-100."""
+    _destroy = lib.rl_tonemap_unit_destroy
+
+    def __init__(self, width, height, device=0):
+        super().__init__()
+        check(lib.rl_tonemap_unit_create(device, width, height, C.byref(self._h)))
+        self.width, self.height, self.device = width, height, device
+
+    def tonemap(self, gather_unit):
+        check(lib.rl_tonemap_unit_tonemap(self._h, gather_unit.handle))
+
+    @property
+    def rgb_buffer(self):
+        out = np.zeros((self.height * self.width, 3), dtype=np.uint8)
+        check(lib.rl_tonemap_unit_rgb(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def srgb_float(self):
+        """(clamped float sRGB before quantisation, max_intensity of find_exposure)."""
+        out = np.zeros((self.height * self.width, 3), dtype=np.float32)
+        mx = C.c_float(0)
+        check(lib.rl_tonemap_unit_srgb_float(self._h, out.ctypes.data_as(C.c_void_p), C.byref(mx)))
+        return out, mx.value
+
+
+class Task:
+    """enum Task (task_scheduler.rs:26-41) by unit ids."""
+
+    def __init__(self, kind=TASK_SLEEP, unit=0, units=()):
+        self.kind, self.unit, self.units = kind, unit, list(units)
+
+    def _to_c(self):
+        t = RlTask()
+        t.kind, t.unit, t.n_units = self.kind, self.unit, len(self.units)
+        for i, u in enumerate(self.units):
+            t.units[i] = u
+        return t
+
+    @classmethod
+    def _from_c(cls, t):
+        return cls(t.kind, t.unit, [t.units[i] for i in range(t.n_units)])
+
+    def __repr__(self):
+        names = ["Sleep", "Trace", "Plot", "Gather", "Tonemap"]
+        if self.kind == TASK_TRACE:
+            return "Trace(%d)" % self.unit
+        if self.kind == TASK_PLOT:
+            return "Plot(%d, %r)" % (self.unit, self.units)
+        if self.kind == TASK_GATHER:
+            return "Gather(%r)" % (self.units,)
+        return names[self.kind]
+
+    def __eq__(self, other):
+        return (self.kind, self.unit, self.units) == (other.kind, other.unit, other.units)
+
+
+class TaskScheduler(_Handle):
+    """task_scheduler.rs:48-325."""
+    _destroy = lib.rl_scheduler_destroy
+
+    def __init__(self, concurrency, tonemap_interval_ms=30000):
+        super().__init__()
+        check(lib.rl_scheduler_create(concurrency, tonemap_interval_ms, C.byref(self._h)))
+
+    def get_new_task(self, completed_task, now_ms=0):
+        c, n = completed_task._to_c(), RlTask()
+        check(lib.rl_scheduler_get_new_task(self._h, C.byref(c), now_ms, C.byref(n)))
+        return Task._from_c(n)
+
+    def performance(self):
+        m, s = C.c_float(0), C.c_float(0)
+        check(lib.rl_scheduler_performance(self._h, C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+
+def math_probe(fn, x, device=0):
+    """Evaluates csrc/rl_math.h function `fn` on the GPU (diagnostics for the parity tests)."""
+    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9}
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros_like(x)
+    check(lib.rl_debug_math_probe(device, names[fn], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))
+    return y

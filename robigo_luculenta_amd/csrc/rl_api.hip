@@ -1,0 +1,650 @@
+// rl_api.hip -- implementation of include/robigo_luculenta.h over the gfx950 kernels.
+//
+// Ordering model: every trace unit owns a blocking HIP stream; plot / gather / tonemap work and all
+// copies run on the device's null stream, which HIP orders against blocking streams, so a fused
+// render followed by a gather needs no explicit event.  Entry points never throw.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/robigo_luculenta.h"
+#include "rl_kernels.hip.h"
+#include "rl_scene.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+
+#define RL_HIP(call)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(RL_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(RL_E_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n) return fail(RL_E_INVALID, "device index out of range");
+    RL_HIP(hipSetDevice(device));
+    return RL_OK;
+}
+
+struct EventPair {
+    hipEvent_t start, stop;
+};
+
+} // namespace
+
+struct RlScene {
+    int device;
+    RlF4* blob;
+    RlSceneLayout lay;
+    size_t staged_bytes;
+};
+
+struct RlTraceUnit {
+    int device;
+    uint32_t id, width, height, n_photons;
+    RlMappedPhoton* photons;
+    unsigned long long* queue; // 3 counters, see rl_trace_kernel
+    hipStream_t stream;
+    int fetch;
+    int cu_count;
+    std::vector<EventPair> pending, pool;
+    double kernel_ms;
+    uint64_t launches;
+};
+
+struct RlPlotUnit {
+    int device;
+    uint32_t id, width, height;
+    float* xyz;
+    bool owns;
+    RlF4* cie;
+};
+
+struct RlGatherUnit {
+    int device;
+    uint32_t width, height;
+    float* acc;
+    float* comp;
+};
+
+struct RlTonemapUnit {
+    int device;
+    uint32_t width, height;
+    uint8_t* rgb;
+    float* srgb;
+    float* max_intensity;
+};
+
+namespace {
+
+int drain_events(RlTraceUnit* u) {
+    for (EventPair& ep : u->pending) {
+        RL_HIP(hipEventSynchronize(ep.stop));
+        float ms = 0.0f;
+        RL_HIP(hipEventElapsedTime(&ms, ep.start, ep.stop));
+        u->kernel_ms += (double)ms;
+        u->pool.push_back(ep);
+    }
+    u->pending.clear();
+    return RL_OK;
+}
+
+int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, float* plot, uint64_t seed,
+                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths) {
+    if (n_paths == 0) return RL_OK;
+    if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
+    RlTraceJob job;
+    job.width = u->width;
+    job.height = u->height;
+    job.aspect_ratio = (float)u->width / (float)u->height; // trace_unit.rs:73
+    job.stream = stream_id;
+    job.seed = seed;
+    job.first_path = first_path;
+    job.n_paths = n_paths;
+
+    const size_t lds_bytes = scene->staged_bytes;
+    bool stage = (u->fetch == RL_FETCH_LDS) && lds_bytes <= 160 * 1024;
+    auto kernel = stage ? rl_trace_kernel<true> : rl_trace_kernel<false>;
+    const size_t dyn = stage ? lds_bytes : 0;
+    if (stage && lds_bytes > 64 * 1024)
+        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int per_cu = 0;
+    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_BLOCK, dyn));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)per_cu;
+    const uint64_t needed = (n_paths + RL_BLOCK - 1) / RL_BLOCK;
+    if (blocks > needed) blocks = needed;
+
+    EventPair ep;
+    if (!u->pool.empty()) {
+        ep = u->pool.back();
+        u->pool.pop_back();
+    } else {
+        RL_HIP(hipEventCreate(&ep.start));
+        RL_HIP(hipEventCreate(&ep.stop));
+    }
+    RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
+    RL_HIP(hipEventRecord(ep.start, u->stream));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
+                       plot, u->queue);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipEventRecord(ep.stop, u->stream));
+    u->pending.push_back(ep);
+    u->launches += 1;
+    if (u->pending.size() > 512) return drain_events(u);
+    return RL_OK;
+}
+
+unsigned grid_for(uint64_t work_items, int cu_count) {
+    uint64_t blocks = (work_items + RL_BLOCK - 1) / RL_BLOCK;
+    const uint64_t cap = (uint64_t)cu_count * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+int cu_count_of(int device, int* out) {
+    hipDeviceProp_t prop;
+    RL_HIP(hipGetDeviceProperties(&prop, device));
+    *out = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return RL_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rl_last_error(void) { return g_error.c_str(); }
+
+int rl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* rl_version(void) { return "robigo-luculenta_amd 0.1 (gfx950)"; }
+
+// ---- scene --------------------------------------------------------------------------------------
+
+int rl_scene_builtin_desc(int which, int param, RlObjectDesc* objects, uint32_t cap, uint32_t* n_objects,
+                          RlCameraDesc* camera) {
+    std::vector<RlObjectDesc> v;
+    RlCameraDesc cam;
+    const uint32_t n = rl_builtin_scene(which, param, &v, &cam);
+    if (n == 0) return fail(RL_E_INVALID, "unknown built-in scene");
+    if (n_objects) *n_objects = n;
+    if (camera) *camera = cam;
+    if (!objects || cap < n) return fail(RL_E_INVALID, "object array too small for the built-in scene");
+    std::memcpy(objects, v.data(), n * sizeof(RlObjectDesc));
+    return RL_OK;
+}
+
+int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    RlFlatScene fs;
+    const char* err = "";
+    int rc = rl_flatten_scene(desc, &fs, &err);
+    if (rc != RL_OK) return fail(rc, err);
+    if ((rc = use_device(device)) != RL_OK) return rc;
+
+    // One blob: spheres | planes | parabs | prisms | objects | cie | sphere_obj (padded to 16 B).
+    std::vector<RlF4> blob;
+    RlSceneLayout lay;
+    std::memset(&lay, 0, sizeof lay);
+    auto append = [&](const std::vector<RlF4>& v) {
+        const uint32_t off = (uint32_t)blob.size();
+        blob.insert(blob.end(), v.begin(), v.end());
+        return off;
+    };
+    append(fs.spheres);
+    lay.off_planes = append(fs.planes);
+    lay.off_parabs = append(fs.parabs);
+    lay.off_prisms = append(fs.prisms);
+    lay.off_objects = append(fs.objects);
+    lay.off_cie = (uint32_t)blob.size();
+    const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
+    blob.insert(blob.end(), cie, cie + RL_CIE_SAMPLES);
+    lay.off_sphere_obj = (uint32_t)blob.size();
+    const size_t so_f4 = (fs.sphere_obj.size() + 3) / 4;
+    blob.resize(blob.size() + so_f4);
+    std::memcpy(blob.data() + lay.off_sphere_obj, fs.sphere_obj.data(), fs.sphere_obj.size() * sizeof(uint32_t));
+    lay.total_f4 = (uint32_t)blob.size();
+    lay.n_spheres = (uint32_t)fs.spheres.size();
+    lay.n_planes = (uint32_t)(fs.planes.size() / 2);
+    lay.n_parabs = (uint32_t)(fs.parabs.size() / 3);
+    lay.n_prisms = (uint32_t)(fs.prisms.size() / 16);
+    lay.n_objects = (uint32_t)(fs.objects.size() / 2);
+    lay.camera = fs.camera;
+    lay.screen_distance = fs.screen_distance;
+
+    RlScene* s = new (std::nothrow) RlScene();
+    if (!s) return fail(RL_E_INVALID, "out of host memory");
+    s->device = device;
+    s->lay = lay;
+    s->staged_bytes = blob.size() * sizeof(RlF4);
+    s->blob = nullptr;
+    hipError_t e = hipMalloc((void**)&s->blob, s->staged_bytes);
+    if (e == hipSuccess) e = hipMemcpy(s->blob, blob.data(), s->staged_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (s->blob) (void)hipFree(s->blob);
+        delete s;
+        return fail(RL_E_HIP, std::string("scene upload: ") + hipGetErrorString(e));
+    }
+    *out = s;
+    return RL_OK;
+}
+
+int rl_scene_destroy(RlScene* scene) {
+    if (!scene) return RL_OK;
+    (void)hipSetDevice(scene->device);
+    (void)hipFree(scene->blob);
+    delete scene;
+    return RL_OK;
+}
+
+// ---- TraceUnit ----------------------------------------------------------------------------------
+
+int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t height, uint32_t n_photons,
+                         RlTraceUnit** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (width == 0 || height == 0 || n_photons == 0) return fail(RL_E_INVALID, "zero-sized trace unit");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    RlTraceUnit* u = new (std::nothrow) RlTraceUnit();
+    if (!u) return fail(RL_E_INVALID, "out of host memory");
+    u->device = device;
+    u->id = id;
+    u->width = width;
+    u->height = height;
+    u->n_photons = n_photons;
+    u->photons = nullptr;
+    u->queue = nullptr;
+    u->stream = nullptr;
+    u->fetch = RL_FETCH_LDS;
+    u->kernel_ms = 0.0;
+    u->launches = 0;
+    u->cu_count = 256;
+    hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));
+    if (e == hipSuccess) e = hipMemset(u->photons, 0, (size_t)n_photons * sizeof(RlMappedPhoton)); // MappedPhoton::new
+    if (e == hipSuccess) e = hipMalloc((void**)&u->queue, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(u->queue, 0, 3 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipStreamCreate(&u->stream);
+    if (e != hipSuccess) {
+        rl_trace_unit_destroy(u);
+        return fail(RL_E_HIP, std::string("trace unit allocation: ") + hipGetErrorString(e));
+    }
+    if ((rc = cu_count_of(device, &u->cu_count)) != RL_OK) {
+        rl_trace_unit_destroy(u);
+        return rc;
+    }
+    *out = u;
+    return RL_OK;
+}
+
+int rl_trace_unit_destroy(RlTraceUnit* u) {
+    if (!u) return RL_OK;
+    (void)hipSetDevice(u->device);
+    if (u->stream) (void)hipStreamSynchronize(u->stream);
+    for (EventPair& ep : u->pending) {
+        (void)hipEventDestroy(ep.start);
+        (void)hipEventDestroy(ep.stop);
+    }
+    for (EventPair& ep : u->pool) {
+        (void)hipEventDestroy(ep.start);
+        (void)hipEventDestroy(ep.stop);
+    }
+    if (u->stream) (void)hipStreamDestroy(u->stream);
+    if (u->photons) (void)hipFree(u->photons);
+    if (u->queue) (void)hipFree(u->queue);
+    delete u;
+    return RL_OK;
+}
+
+int rl_trace_unit_set_fetch(RlTraceUnit* u, int primitive_fetch) {
+    if (!u) return fail(RL_E_INVALID, "null trace unit");
+    if (primitive_fetch != RL_FETCH_LDS && primitive_fetch != RL_FETCH_GLOBAL) return fail(RL_E_INVALID, "unknown fetch mode");
+    u->fetch = primitive_fetch;
+    return RL_OK;
+}
+
+int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
+    if (!u || !scene) return fail(RL_E_INVALID, "null handle");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    if ((rc = launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons)) != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
+    return RL_OK;
+}
+
+int rl_trace_unit_render_fused(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
+                               uint64_t first_path_index, uint64_t n_paths) {
+    if (!u || !scene || !plot) return fail(RL_E_INVALID, "null handle");
+    if (plot->device != u->device || plot->width != u->width || plot->height != u->height)
+        return fail(RL_E_STATE, "plot unit does not match the trace unit (device or size)");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    return launch_trace(u, scene, nullptr, plot->xyz, seed, stream, first_path_index, n_paths);
+}
+
+int rl_trace_unit_sync(RlTraceUnit* u) {
+    if (!u) return fail(RL_E_INVALID, "null trace unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
+    return drain_events(u);
+}
+
+int rl_trace_unit_photons(RlTraceUnit* u, RlMappedPhoton* out) {
+    if (!u || !out) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
+    RL_HIP(hipMemcpy(out, u->photons, (size_t)u->n_photons * sizeof(RlMappedPhoton), hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+int rl_trace_unit_stats(RlTraceUnit* u, uint64_t* paths, uint64_t* segments, double* kernel_ms) {
+    if (!u) return fail(RL_E_INVALID, "null trace unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
+    if ((rc = drain_events(u)) != RL_OK) return rc;
+    unsigned long long q[3];
+    RL_HIP(hipMemcpy(q, u->queue, sizeof q, hipMemcpyDeviceToHost));
+    if (segments) *segments = q[1];
+    if (paths) *paths = q[2];
+    if (kernel_ms) *kernel_ms = u->kernel_ms;
+    return RL_OK;
+}
+
+// ---- PlotUnit -----------------------------------------------------------------------------------
+
+int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height, float* external_xyz, RlPlotUnit** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (width == 0 || height == 0) return fail(RL_E_INVALID, "zero-sized plot unit");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    RlPlotUnit* u = new (std::nothrow) RlPlotUnit();
+    if (!u) return fail(RL_E_INVALID, "out of host memory");
+    u->device = device;
+    u->id = id;
+    u->width = width;
+    u->height = height;
+    u->xyz = external_xyz;
+    u->owns = external_xyz == nullptr;
+    u->cie = nullptr;
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    hipError_t e = hipSuccess;
+    if (u->owns) {
+        e = hipMalloc((void**)&u->xyz, bytes);
+        if (e == hipSuccess) e = hipMemset(u->xyz, 0, bytes);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&u->cie, sizeof RL_CIE1931_XYZ0);
+    if (e == hipSuccess) e = hipMemcpy(u->cie, RL_CIE1931_XYZ0, sizeof RL_CIE1931_XYZ0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        rl_plot_unit_destroy(u);
+        return fail(RL_E_HIP, std::string("plot unit allocation: ") + hipGetErrorString(e));
+    }
+    *out = u;
+    return RL_OK;
+}
+
+int rl_plot_unit_destroy(RlPlotUnit* u) {
+    if (!u) return RL_OK;
+    (void)hipSetDevice(u->device);
+    if (u->owns && u->xyz) (void)hipFree(u->xyz);
+    if (u->cie) (void)hipFree(u->cie);
+    delete u;
+    return RL_OK;
+}
+
+int rl_plot_unit_plot(RlPlotUnit* u, RlTraceUnit* const* trace_units, uint32_t n_trace_units) {
+    if (!u || (!trace_units && n_trace_units)) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    int cus = 256;
+    if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
+    const float aspect = (float)u->width / (float)u->height; // plot_unit.rs:48
+    for (uint32_t k = 0; k < n_trace_units; ++k) {           // app.rs:138-140
+        RlTraceUnit* t = trace_units[k];
+        if (!t || t->device != u->device) return fail(RL_E_STATE, "trace unit missing or on another device");
+        hipLaunchKernelGGL(rl_plot_kernel, dim3(grid_for(t->n_photons, cus)), dim3(RL_BLOCK), 0, 0, t->photons, t->n_photons,
+                           u->cie, u->width, u->height, aspect, u->xyz);
+        RL_HIP(hipGetLastError());
+    }
+    return RL_OK;
+}
+
+int rl_plot_unit_clear(RlPlotUnit* u) {
+    if (!u) return fail(RL_E_INVALID, "null plot unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipMemsetAsync(u->xyz, 0, (size_t)u->width * u->height * 3 * sizeof(float), 0));
+    return RL_OK;
+}
+
+int rl_plot_unit_device_buffer(RlPlotUnit* u, float** device_xyz) {
+    if (!u || !device_xyz) return fail(RL_E_INVALID, "null argument");
+    *device_xyz = u->xyz;
+    return RL_OK;
+}
+
+int rl_plot_unit_download(RlPlotUnit* u, RlVector3* out) {
+    if (!u || !out) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipMemcpy(out, u->xyz, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+// ---- GatherUnit ---------------------------------------------------------------------------------
+
+int rl_gather_unit_create(int device, uint32_t width, uint32_t height, RlGatherUnit** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (width == 0 || height == 0) return fail(RL_E_INVALID, "zero-sized gather unit");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    RlGatherUnit* u = new (std::nothrow) RlGatherUnit();
+    if (!u) return fail(RL_E_INVALID, "out of host memory");
+    u->device = device;
+    u->width = width;
+    u->height = height;
+    u->acc = u->comp = nullptr;
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    hipError_t e = hipMalloc((void**)&u->acc, bytes);
+    if (e == hipSuccess) e = hipMemset(u->acc, 0, bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&u->comp, bytes);
+    if (e == hipSuccess) e = hipMemset(u->comp, 0, bytes);
+    if (e != hipSuccess) {
+        rl_gather_unit_destroy(u);
+        return fail(RL_E_HIP, std::string("gather unit allocation: ") + hipGetErrorString(e));
+    }
+    *out = u;
+    return RL_OK;
+}
+
+int rl_gather_unit_destroy(RlGatherUnit* u) {
+    if (!u) return RL_OK;
+    (void)hipSetDevice(u->device);
+    if (u->acc) (void)hipFree(u->acc);
+    if (u->comp) (void)hipFree(u->comp);
+    delete u;
+    return RL_OK;
+}
+
+int rl_gather_unit_accumulate(RlGatherUnit* u, RlPlotUnit* plot) {
+    if (!u || !plot) return fail(RL_E_INVALID, "null handle");
+    if (plot->device != u->device || plot->width != u->width || plot->height != u->height)
+        return fail(RL_E_STATE, "plot unit does not match the gather unit (device or size)");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    int cus = 256;
+    if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
+    const uint64_t n_floats = (uint64_t)u->width * u->height * 3;
+    hipLaunchKernelGGL(rl_gather_kernel, dim3(grid_for(n_floats / 4 + 1, cus)), dim3(RL_BLOCK), 0, 0, u->acc, u->comp, plot->xyz,
+                       n_floats);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int rl_gather_unit_download(RlGatherUnit* u, RlVector3* tristimulus, RlVector3* compensation) {
+    if (!u) return fail(RL_E_INVALID, "null gather unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    const size_t bytes = (size_t)u->width * u->height * sizeof(RlVector3);
+    if (tristimulus) RL_HIP(hipMemcpy(tristimulus, u->acc, bytes, hipMemcpyDeviceToHost));
+    if (compensation) RL_HIP(hipMemcpy(compensation, u->comp, bytes, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+int rl_gather_unit_save(RlGatherUnit* u, const char* path) {
+    if (!u || !path) return fail(RL_E_INVALID, "null argument");
+    const size_t n = (size_t)u->width * u->height;
+    std::vector<RlVector3> host(2 * n);
+    int rc = rl_gather_unit_download(u, host.data(), host.data() + n);
+    if (rc != RL_OK) return rc;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RL_E_IO, std::string("failed to open file ") + path);
+    const size_t written = std::fwrite(host.data(), sizeof(RlVector3), 2 * n, f);
+    const int closed = std::fclose(f);
+    if (written != 2 * n || closed != 0) return fail(RL_E_IO, std::string("failed to write raw buffer ") + path);
+    return RL_OK;
+}
+
+int rl_gather_unit_load(RlGatherUnit* u, const char* path) {
+    if (!u || !path) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(RL_E_IO, std::string("failed to open file ") + path);
+    const size_t n = (size_t)u->width * u->height;
+    std::vector<RlVector3> host(2 * n);
+    // read_into semantics (read.rs:20-32): a short file leaves the tail as it was.
+    if ((rc = rl_gather_unit_download(u, host.data(), host.data() + n)) != RL_OK) {
+        std::fclose(f);
+        return rc;
+    }
+    (void)std::fread(host.data(), 1, 2 * n * sizeof(RlVector3), f);
+    std::fclose(f);
+    RL_HIP(hipMemcpy(u->acc, host.data(), n * sizeof(RlVector3), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(u->comp, host.data() + n, n * sizeof(RlVector3), hipMemcpyHostToDevice));
+    return RL_OK;
+}
+
+// ---- TonemapUnit --------------------------------------------------------------------------------
+
+int rl_tonemap_unit_create(int device, uint32_t width, uint32_t height, RlTonemapUnit** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (width == 0 || height == 0) return fail(RL_E_INVALID, "zero-sized tonemap unit");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    RlTonemapUnit* u = new (std::nothrow) RlTonemapUnit();
+    if (!u) return fail(RL_E_INVALID, "out of host memory");
+    u->device = device;
+    u->width = width;
+    u->height = height;
+    u->rgb = nullptr;
+    u->srgb = nullptr;
+    u->max_intensity = nullptr;
+    const size_t n = (size_t)width * height * 3;
+    hipError_t e = hipMalloc((void**)&u->rgb, n);
+    if (e == hipSuccess) e = hipMemset(u->rgb, 0, n);
+    if (e == hipSuccess) e = hipMalloc((void**)&u->srgb, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(u->srgb, 0, n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&u->max_intensity, sizeof(float));
+    if (e == hipSuccess) e = hipMemset(u->max_intensity, 0, sizeof(float));
+    if (e != hipSuccess) {
+        rl_tonemap_unit_destroy(u);
+        return fail(RL_E_HIP, std::string("tonemap unit allocation: ") + hipGetErrorString(e));
+    }
+    *out = u;
+    return RL_OK;
+}
+
+int rl_tonemap_unit_destroy(RlTonemapUnit* u) {
+    if (!u) return RL_OK;
+    (void)hipSetDevice(u->device);
+    if (u->rgb) (void)hipFree(u->rgb);
+    if (u->srgb) (void)hipFree(u->srgb);
+    if (u->max_intensity) (void)hipFree(u->max_intensity);
+    delete u;
+    return RL_OK;
+}
+
+int rl_tonemap_unit_tonemap(RlTonemapUnit* u, RlGatherUnit* gather) {
+    if (!u || !gather) return fail(RL_E_INVALID, "null handle");
+    if (gather->device != u->device || gather->width != u->width || gather->height != u->height)
+        return fail(RL_E_STATE, "gather unit does not match the tonemap unit (device or size)");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    int cus = 256;
+    if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
+    const uint32_t n_pixels = u->width * u->height;
+    hipLaunchKernelGGL(rl_exposure_kernel, dim3(1), dim3(64), 0, 0, gather->acc, n_pixels, (float)n_pixels, u->max_intensity);
+    RL_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rl_tonemap_kernel, dim3(grid_for(n_pixels, cus)), dim3(RL_BLOCK), 0, 0, gather->acc, n_pixels,
+                       u->max_intensity, u->rgb, u->srgb);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int rl_tonemap_unit_rgb(RlTonemapUnit* u, uint8_t* out) {
+    if (!u || !out) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipMemcpy(out, u->rgb, (size_t)u->width * u->height * 3, hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+int rl_tonemap_unit_srgb_float(RlTonemapUnit* u, float* out, float* max_intensity) {
+    if (!u) return fail(RL_E_INVALID, "null tonemap unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    if (out) RL_HIP(hipMemcpy(out, u->srgb, (size_t)u->width * u->height * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (max_intensity) RL_HIP(hipMemcpy(max_intensity, u->max_intensity, sizeof(float), hipMemcpyDeviceToHost));
+    return RL_OK;
+}
+
+// ---- device-side math probe (tests) -------------------------------------------------------------
+
+// Not part of the reference's interface: evaluates csrc/rl_math.h on the GPU so the tests can
+// verify that hipcc and g++ agree bit-for-bit.  fn as in rl_math_probe_kernel.
+int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n) {
+    if (!x || !y || n == 0) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    float *dx = nullptr, *dy = nullptr;
+    RL_HIP(hipMalloc((void**)&dx, n * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&dy, n * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(dx, x, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rl_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, fn, dx, dy, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(y, dy, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) return fail(RL_E_HIP, std::string("math probe: ") + hipGetErrorString(e));
+    return RL_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,297 @@
+// rl_kernels.hip.h -- the gfx950 kernels: persistent-wavefront trace (+ fused CIE splat), plot,
+// Kahan gather, exposure, tonemap.  Included once by rl_api.hip.
+//
+// Trace kernel design (wave64, CDNA4):
+//   * one live path per lane; a lane whose path ended takes the next path index from its wave's
+//     chunk of a global work queue (one atomic per CHUNK paths per wave) and regenerates its camera
+//     ray, so the intersection scan -- >95 % of the instructions -- always runs with full exec mask
+//     until the queue drains;
+//   * the scene (16-byte records, rl_scene.h) is either staged in LDS by the workgroup and read with
+//     wave-uniform ds_read_b128 broadcasts (RL_FETCH_LDS) or read straight from global memory with
+//     wave-uniform addresses, which the compiler turns into scalar s_load_dwordx4 through the scalar
+//     cache (RL_FETCH_GLOBAL);
+//   * results leave either as MappedPhoton records (un-fused, bit-comparable with the CPU) or as
+//     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
+//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rl_cie1931.h"
+#include "rl_core.h"
+
+#define RL_BLOCK 256
+#define RL_CHUNK 256ull // paths a wave takes from the global queue at a time
+
+struct RlSceneLayout {
+    // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
+    uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cie, off_sphere_obj, total_f4;
+    uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects;
+    RlCameraDesc camera;
+    float screen_distance;
+};
+
+struct RlTraceJob {
+    uint32_t width, height;
+    float aspect_ratio;
+    uint32_t stream;
+    uint64_t seed;
+    uint64_t first_path;
+    uint64_t n_paths;
+};
+
+// queue[0] = next unassigned path offset of this launch (zeroed before each launch),
+// queue[1] = cumulative segments, queue[2] = cumulative paths.
+template <bool STAGE_LDS>
+__global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
+                                                            RlTraceJob job, RlMappedPhoton* __restrict__ photons,
+                                                            float* __restrict__ plot,
+                                                            unsigned long long* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
+    const RlF4* base = scene;
+    if (STAGE_LDS) {
+        for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_BLOCK) smem[i] = scene[i];
+        __syncthreads();
+        base = smem;
+    }
+    RlSceneView sv;
+    sv.spheres = base;
+    sv.planes = base + lay.off_planes;
+    sv.parabs = base + lay.off_parabs;
+    sv.prisms = base + lay.off_prisms;
+    sv.objects = base + lay.off_objects;
+    sv.cie = base + lay.off_cie;
+    sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
+    sv.n_spheres = lay.n_spheres;
+    sv.n_planes = lay.n_planes;
+    sv.n_parabs = lay.n_parabs;
+    sv.n_prisms = lay.n_prisms;
+    sv.n_objects = lay.n_objects;
+    sv.camera = lay.camera;
+    sv.screen_distance = lay.screen_distance;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lane_below = (1ull << lane) - 1ull;
+
+    uint64_t chunk_next = 0, chunk_end = 0; // wave-uniform
+    bool drained = false;                   // wave-uniform
+    bool active = false;
+    uint64_t my_offset = 0;
+    RlPath p;
+    uint32_t segments = 0, paths_done = 0;
+
+    for (;;) {
+        const uint64_t need = __ballot(!active);
+        if (need != 0 && !drained) {
+            const uint32_t cnt = (uint32_t)__popcll(need);
+            const uint32_t rank = (uint32_t)__popcll(need & lane_below);
+            const uint64_t avail = chunk_end - chunk_next;
+            const uint64_t base0 = chunk_next;
+            uint64_t base1 = 0;
+            if (avail < cnt) {
+                unsigned long long b = 0;
+                if (lane == 0) b = atomicAdd(&queue[0], RL_CHUNK);
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+                base1 = ((uint64_t)hi << 32) | lo;
+                chunk_next = base1 + (cnt - avail);
+                chunk_end = base1 + RL_CHUNK;
+            } else {
+                chunk_next += cnt;
+            }
+            if (!active) {
+                const uint64_t offset = (rank < avail) ? base0 + rank : base1 + (rank - avail);
+                if (offset < job.n_paths) {
+                    my_offset = offset;
+                    rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, job.first_path + offset, &p);
+                    active = true;
+                }
+            }
+            if (chunk_next >= job.n_paths) drained = true;
+        }
+        if (__ballot(active) == 0) break;
+        if (active) {
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            segments += 1;
+            float value;
+            if (rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value)) {
+                active = false;
+                paths_done += 1;
+                if (photons) {
+                    RlMappedPhoton ph;
+                    ph.x = p.sx;
+                    ph.y = p.sy;
+                    ph.probability = value;
+                    ph.wavelength = p.wavelength;
+                    photons[my_offset] = ph;
+                }
+                if (plot && value != 0.0f) { // plot_unit.rs:87-95 (adding +0 is the identity)
+                    const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, p.wavelength), value);
+                    const RlSplat s = rl_splat_weights(job.width, job.height, job.aspect_ratio, p.sx, p.sy);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float* px = plot + 3ull * s.idx[k];
+                        unsafeAtomicAdd(px + 0, cie.x * s.w[k]);
+                        unsafeAtomicAdd(px + 1, cie.y * s.w[k]);
+                        unsafeAtomicAdd(px + 2, cie.z * s.w[k]);
+                    }
+                }
+            }
+        }
+    }
+    // One atomic per wave for the counters.
+    uint32_t s = segments, d = paths_done;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        d += __shfl_down(d, off);
+    }
+    if (lane == 0) {
+        atomicAdd(&queue[1], (unsigned long long)s);
+        atomicAdd(&queue[2], (unsigned long long)d);
+    }
+}
+
+// PlotUnit::plot (plot_unit.rs:87-95) for the un-fused path: one photon per thread.
+__global__ __launch_bounds__(RL_BLOCK) void rl_plot_kernel(const RlMappedPhoton* __restrict__ photons, uint32_t n,
+                                                           const RlF4* __restrict__ cie, uint32_t width, uint32_t height,
+                                                           float aspect_ratio, float* __restrict__ plot) {
+    __shared__ RlF4 s_cie[RL_CIE_SAMPLES];
+    for (uint32_t i = threadIdx.x; i < RL_CIE_SAMPLES; i += RL_BLOCK) s_cie[i] = cie[i];
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * RL_BLOCK + threadIdx.x; i < n; i += gridDim.x * RL_BLOCK) {
+        const RlMappedPhoton ph = photons[i];
+        if (ph.probability == 0.0f) continue;
+        const RlF3 c = rl_mul(rl_tristimulus(s_cie, ph.wavelength), ph.probability);
+        const RlSplat s = rl_splat_weights(width, height, aspect_ratio, ph.x, ph.y);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float* px = plot + 3ull * s.idx[k];
+            unsafeAtomicAdd(px + 0, c.x * s.w[k]);
+            unsafeAtomicAdd(px + 1, c.y * s.w[k]);
+            unsafeAtomicAdd(px + 2, c.z * s.w[k]);
+        }
+    }
+}
+
+// GatherUnit::accumulate + PlotUnit::clear (gather_unit.rs:49-64, plot_unit.rs:98-102), one float
+// component per lane-element, 16 bytes per lane per buffer.  Kahan order is fixed; nothing here may
+// be re-associated (no fast-math).
+__global__ __launch_bounds__(RL_BLOCK) void rl_gather_kernel(float* __restrict__ acc, float* __restrict__ comp,
+                                                             float* __restrict__ px, uint64_t n_floats) {
+    const uint64_t n4 = n_floats / 4;
+    float4* acc4 = (float4*)acc;
+    float4* comp4 = (float4*)comp;
+    float4* px4 = (float4*)px;
+    for (uint64_t i = (uint64_t)blockIdx.x * RL_BLOCK + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * RL_BLOCK) {
+        float4 a = acc4[i], c = comp4[i];
+        const float4 p = px4[i];
+        float av[4] = {a.x, a.y, a.z, a.w}, cv[4] = {c.x, c.y, c.z, c.w};
+        const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float extra = pv[k] - cv[k];
+            const float sum = av[k] + extra;
+            cv[k] = (sum - av[k]) - extra;
+            av[k] = sum;
+        }
+        acc4[i] = make_float4(av[0], av[1], av[2], av[3]);
+        comp4[i] = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        px4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_floats & 3)) {
+        const uint64_t i = n4 * 4 + threadIdx.x;
+        const float extra = px[i] - comp[i];
+        const float sum = acc[i] + extra;
+        comp[i] = (sum - acc[i]) - extra;
+        acc[i] = sum;
+        px[i] = 0.0f;
+    }
+}
+
+// TonemapUnit::find_exposure (tonemap_unit.rs:55-69).  The reference sums Y and Y^2 sequentially in
+// f32 over all pixels; a tree reduction would move max_intensity at the 1e-4 level and with it every
+// output pixel.  One wave keeps the reference's order: all 64 lanes stream tiles of Y into LDS with
+// coalesced loads, then lane 0 accumulates sum(Y) and lane 1 sum(Y*Y) in pixel order (the two chains
+// share one instruction stream).  Runs once per tonemap (every 30 s in the reference).
+#define RL_EXPOSURE_TILE 4096
+__global__ __launch_bounds__(64) void rl_exposure_kernel(const float* __restrict__ xyz, uint32_t n_pixels, float n_as_float,
+                                                         float* __restrict__ out_max) {
+    __shared__ float tile[RL_EXPOSURE_TILE];
+    const uint32_t lane = threadIdx.x;
+    float total = 0.0f;
+    for (uint32_t start = 0; start < n_pixels; start += RL_EXPOSURE_TILE) {
+        const uint32_t count = min((uint32_t)RL_EXPOSURE_TILE, n_pixels - start);
+        for (uint32_t i = lane; i < count; i += 64) tile[i] = xyz[3ull * (start + i) + 1];
+        __syncthreads();
+        if (lane < 2) {
+            for (uint32_t i = 0; i < count; ++i) {
+                const float y = tile[i];
+                total = total + (lane == 0 ? y : y * y);
+            }
+        }
+        __syncthreads();
+    }
+    const float sum_y = __shfl(total, 0);
+    const float sum_yy = __shfl(total, 1);
+    if (lane == 0) {
+        const float mean = sum_y / n_as_float;
+        const float sqr_mean = sum_yy / n_as_float;
+        const float variance = sqr_mean - mean * mean;
+        out_max[0] = mean + sqrtf(variance);
+    }
+}
+
+// srgb.rs:20-26
+__device__ __forceinline__ float rl_gamma_correct(float f) {
+    if (f <= 0.0031308f) return 12.92f * f;
+    return 1.055f * rl_powf(f, 1.0f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ float rl_clamp01(float x) { // tonemap_unit.rs:34-38
+    if (x < 0.0f) return 0.0f;
+    if (1.0f < x) return 1.0f;
+    return x;
+}
+
+// TonemapUnit::tonemap's pixel loop (tonemap_unit.rs:79-99) + srgb::transform (srgb.rs:29-41).
+__global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __restrict__ xyz, uint32_t n_pixels,
+                                                              const float* __restrict__ max_intensity_ptr,
+                                                              uint8_t* __restrict__ rgb, float* __restrict__ srgb) {
+    const float max_intensity = max_intensity_ptr[0];
+    const float ln_4 = rl_logf(4.0f);
+    for (uint32_t i = blockIdx.x * RL_BLOCK + threadIdx.x; i < n_pixels; i += gridDim.x * RL_BLOCK) {
+        const float cx = rl_logf(xyz[3ull * i + 0] / max_intensity + 1.0f) / ln_4;
+        const float cy = rl_logf(xyz[3ull * i + 1] / max_intensity + 1.0f) / ln_4;
+        const float cz = rl_logf(xyz[3ull * i + 2] / max_intensity + 1.0f) / ln_4;
+        const float r = rl_clamp01(rl_gamma_correct(3.2406f * cx - 1.5372f * cy - 0.4986f * cz));
+        const float g = rl_clamp01(rl_gamma_correct(-0.9689f * cx + 1.8758f * cy + 0.0415f * cz));
+        const float b = rl_clamp01(rl_gamma_correct(0.0557f * cx - 0.2040f * cy + 1.0570f * cz));
+        srgb[3ull * i + 0] = r;
+        srgb[3ull * i + 1] = g;
+        srgb[3ull * i + 2] = b;
+        rgb[3ull * i + 0] = (uint8_t)(r * 255.0f);
+        rgb[3ull * i + 1] = (uint8_t)(g * 255.0f);
+        rgb[3ull * i + 2] = (uint8_t)(b * 255.0f);
+    }
+}
+
+// Evaluates rl_math.h on the device so tests can compare it bit-for-bit with the host build.
+// fn: 0 sin 1 cos 2 tan 3 exp 4 log 5 acos 6 sf10 ior 7 sqrt 8 a/b (y = x[i] / x[i+1 mod n]) 9 powf(x, 1/2.4)
+__global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float* __restrict__ y, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float r = 0.0f;
+    switch (fn) {
+    case 0: r = rl_sinf(v); break;
+    case 1: r = rl_cosf(v); break;
+    case 2: r = rl_tanf(v); break;
+    case 3: r = rl_expf(v); break;
+    case 4: r = rl_logf(v); break;
+    case 5: r = rl_acosf(v); break;
+    case 6: r = rl_sf10_ior(v); break;
+    case 7: r = sqrtf(v); break;
+    case 8: r = v / x[(i + 1) % n]; break;
+    case 9: r = rl_powf(v, 1.0f / 2.4f); break;
+    }
+    y[i] = r;
+}

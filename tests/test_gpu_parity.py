@@ -1,0 +1,204 @@
+"""GPU parity tests proper: the HIP path through the C ABI against the CPU oracle.  Integer-like
+outputs (per-photon records, Kahan buffers, exposure, tonemapped bytes) are compared BIT-EXACTLY;
+only the atomically accumulated XYZ splat, whose summation order is not deterministic, gets a
+float tolerance (stated at each assert)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+R = pytest.importorskip("robigo_luculenta_amd")
+
+
+def _ocam(cam):
+    return O.RlCameraDesc.from_buffer_copy(bytes(cam))
+
+
+@pytest.fixture(scope="module")
+def demo():
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    return objs, cam, R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+
+
+def test_device_present():
+    assert R.device_count() >= 1
+
+
+@pytest.mark.parametrize("fn,lo,hi", [("sin", -20, 20), ("cos", -20, 20), ("tan", 0.1, 1.4), ("exp", -100, 10),
+                                      ("log", 1e-6, 100), ("acos", -0.999, 0.999)])
+def test_math_header_bit_exact_on_device(fn, lo, hi):
+    rng = np.random.default_rng(7)
+    x = rng.uniform(lo, hi, 1 << 16).astype(np.float32)
+    got = R.math_probe(fn, x)
+    want = O.math_f32(fn, x)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_ieee_sqrt_div_and_f64_islands_on_device():
+    rng = np.random.default_rng(8)
+    x = np.exp(rng.uniform(-30, 30, 1 << 16)).astype(np.float32)
+    assert R.math_probe("sqrt", x).tobytes() == np.sqrt(x).tobytes()
+    assert R.math_probe("div", x).tobytes() == (x / np.roll(x, -1)).tobytes()
+    lam = rng.uniform(380, 780, 1 << 16).astype(np.float32)
+    want = np.array([O.lib().oracle_sf10_ior(float(v)) for v in lam[:4096]], dtype=np.float32)
+    assert R.math_probe("sf10", lam[:4096]).tobytes() == want.tobytes()
+    g = rng.uniform(0.0031308, 4.0, 1 << 14).astype(np.float32)
+    wantg = np.zeros_like(g)
+    O.lib().oracle_powf(O.ptr(g), C.c_float(np.float32(1.0) / np.float32(2.4)), O.ptr(wantg), g.size)
+    assert R.math_probe("gamma", g).tobytes() == wantg.tobytes()
+
+
+@pytest.mark.parametrize("fetch", [R.FETCH_LDS, R.FETCH_GLOBAL])
+def test_trace_photons_bit_exact_demo(demo, fetch):
+    objs, cam, scene, oscene = demo
+    W, H, N = 1280, 720, 1 << 16
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    t.set_fetch(fetch)
+    for seed, stream, first in [(1, 0, 0), (2, 3, 5_000_000_000)]:
+        t.render(scene, seed=seed, stream=stream, first_path_index=first)
+        got = t.mapped_photons
+        want, segs = oscene.render(W, H, seed, stream, first, N, threads=8)
+        assert got.tobytes() == want.tobytes()
+    paths, segments, ms = t.stats()
+    assert paths == 2 * N
+
+
+def test_trace_photons_bit_exact_glass_and_replicated():
+    W, H, N = 640, 360, 1 << 15
+    for which, param in [(R.SCENE_GLASS_STRESS, 0), (R.SCENE_DEMO, 158)]:
+        objs, cam = R.builtin_scene_desc(which, param)
+        scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+        for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+            t = R.TraceUnit(0, W, H, n_photons=N)
+            t.set_fetch(fetch)
+            t.render(scene, seed=9, stream=1, first_path_index=123)
+            want, segs = oscene.render(W, H, 9, 1, 123, N, threads=8)
+            assert t.mapped_photons.tobytes() == want.tobytes()
+            assert t.stats()[1] == segs
+
+
+def test_ragged_batch_sizes(demo):
+    objs, cam, scene, oscene = demo
+    for n in (1, 63, 65, 257, 1000):
+        t = R.TraceUnit(0, 64, 36, n_photons=n)
+        t.render(scene, seed=4, stream=0, first_path_index=77)
+        want, _ = oscene.render(64, 36, 4, 0, 77, n)
+        assert t.mapped_photons.tobytes() == want.tobytes()
+
+
+def test_plot_fused_and_unfused_match_oracle(demo):
+    objs, cam, scene, oscene = demo
+    W, H, N = 320, 180, 1 << 18
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    t.render(scene, seed=1, stream=0, first_path_index=0)
+    photons = t.mapped_photons
+    want = O.plot(W, H, photons)
+    p = R.PlotUnit(0, W, H)
+    p.plot([t])
+    got = p.tristimulus_buffer
+    # f32 atomics commute but do not associate: tolerance = a few ulps of the per-pixel sum.
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale + 1e-6 * np.abs(want).max()
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-6 * scale)
+    # fused: same photons splatted straight from the trace kernel
+    p2 = R.PlotUnit(1, W, H)
+    t.render_fused(scene, p2, N, seed=1, stream=0, first_path_index=0)
+    t.sync()
+    got2 = p2.tristimulus_buffer
+    assert np.allclose(got2, want, rtol=2e-5, atol=1e-6 * scale)
+    # clear
+    p2.clear()
+    assert not p2.tristimulus_buffer.any()
+
+
+def test_gather_kahan_bit_exact_and_clears_plot(demo):
+    objs, cam, scene, oscene = demo
+    W, H, N = 160, 90, 1 << 16
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    p = R.PlotUnit(0, W, H)
+    g = R.GatherUnit(W, H)
+    acc = np.zeros((W * H, 3), np.float32)
+    comp = np.zeros_like(acc)
+    for k in range(3):
+        t.render(scene, seed=1, stream=0, first_path_index=k * N)
+        p.plot([t])
+        px = p.tristimulus_buffer
+        g.accumulate(p)
+        O.accumulate(acc, comp, px)
+        assert not p.tristimulus_buffer.any()  # unit.clear(), app.rs:147
+    assert g.tristimulus_buffer.tobytes() == acc.tobytes()
+    assert g.compensation_buffer.tobytes() == comp.tobytes()
+
+
+def test_checkpoint_round_trip(demo, tmp_path):
+    objs, cam, scene, oscene = demo
+    W, H, N = 64, 36, 1 << 14
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    p = R.PlotUnit(0, W, H)
+    g = R.GatherUnit(W, H)
+    t.render(scene, seed=3)
+    p.plot([t])
+    g.accumulate(p)
+    path = str(tmp_path / "buffer.raw")
+    g.save(path)
+    raw = np.fromfile(path, dtype=np.float32)
+    assert raw.size == 2 * W * H * 3  # gather_unit.rs:68-78: headerless, tristimulus then compensation
+    assert raw[: W * H * 3].tobytes() == g.tristimulus_buffer.tobytes()
+    g2 = R.GatherUnit(W, H)
+    g2.load(path)
+    assert g2.tristimulus_buffer.tobytes() == g.tristimulus_buffer.tobytes()
+    assert g2.compensation_buffer.tobytes() == g.compensation_buffer.tobytes()
+    # short file leaves the tail untouched (read.rs:20-32)
+    raw[: W * H * 3 // 2].tofile(path)
+    g3 = R.GatherUnit(W, H)
+    g3.load(path)
+    got = g3.tristimulus_buffer.reshape(-1)
+    assert got[: W * H * 3 // 2].tobytes() == raw[: W * H * 3 // 2].tobytes() and not got[W * H * 3 // 2:].any()
+
+
+def test_tonemap_bit_exact_given_same_xyz(demo):
+    objs, cam, scene, oscene = demo
+    W, H, N = 320, 180, 1 << 19
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    p = R.PlotUnit(0, W, H)
+    g = R.GatherUnit(W, H)
+    t.render(scene, seed=5)
+    p.plot([t])
+    g.accumulate(p)
+    tm = R.TonemapUnit(W, H)
+    tm.tonemap(g)
+    xyz = g.tristimulus_buffer
+    rgb, srgb, mx = O.tonemap(xyz, W, H)
+    got_srgb, got_mx = tm.srgb_float()
+    assert np.float32(got_mx).tobytes() == np.float32(mx).tobytes()  # sequential f32 sums, tonemap_unit.rs:55-69
+    assert got_srgb.tobytes() == srgb.tobytes()
+    assert tm.rgb_buffer.tobytes() == rgb.tobytes()
+
+
+def test_end_to_end_image_within_1e3(demo):
+    """north_star: sRGB within 1e-3 per channel of the CPU path at matched seed (float sRGB before
+    the *255 quantisation)."""
+    objs, cam, scene, oscene = demo
+    W, H = 160, 90
+    N = 1 << 18
+    batches = 8
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    p = R.PlotUnit(0, W, H)
+    g = R.GatherUnit(W, H)
+    acc = np.zeros((W * H, 3), np.float32)
+    comp = np.zeros_like(acc)
+    for k in range(batches):
+        t.render_fused(scene, p, N, seed=1, stream=0, first_path_index=k * N)
+        g.accumulate(p)
+        photons, _ = oscene.render(W, H, 1, 0, k * N, N, threads=8)
+        O.accumulate(acc, comp, O.plot(W, H, photons))
+    tm = R.TonemapUnit(W, H)
+    tm.tonemap(g)
+    got, _ = tm.srgb_float()
+    _, want, _ = O.tonemap(acc, W, H)
+    assert np.abs(got - want).max() <= 1e-3
+    assert np.abs(tm.rgb_buffer.astype(int) - (want * 255).astype(np.uint8).astype(int)).max() <= 1
