@@ -247,6 +247,18 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     return rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
 }
 
+// Conservative cull for a hexagonal prism (not in the reference): a valid hit lies on the prism's
+// surface, hence inside its bounding sphere `b` = {centre, radius^2} (radius inflated by 5 %, see
+// rl_scene.cpp).  Returns false only when the ray certainly misses the sphere in front of its origin.
+RL_HD bool rl_prism_bound_pass(RlF4 b, RlF3 o, RlF3 dir) {
+    const float cox = b.x - o.x, coy = b.y - o.y, coz = b.z - o.z;
+    const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
+    const float c = (cox * cox + coy * coy + coz * coz) - b.w;
+    const float dlen2 = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z; // glass leaves directions un-normalised
+    // inside the sphere, or the line reaches it ahead of the origin (1e-3 relative slack on the discriminant)
+    return !(c > 0.0f) || (dd > 0.0f && dd * dd >= c * dlen2 * 0.999f);
+}
+
 RL_HD bool rl_nearer(float t, uint32_t obj, const RlHit& best) {
     return t < best.t || (t == best.t && obj < best.obj);
 }
@@ -305,7 +317,8 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
     }
     // Hexagonal prisms.
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
-        const RlF4* pr = sv.prisms + 16 * i;
+        const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * i;
+        if (!rl_prism_bound_pass(pr[16], o, dir)) continue;
         const RlCand c = rl_hex_prism(pr, o, dir);
         const uint32_t obj = rl_f2u(pr[1].w);
         if (c.t >= 0.0f && rl_nearer(c.t, obj, best)) {
@@ -340,7 +353,7 @@ RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit
         const RlF3 plane_pr = rl_sub(local_pos, rl_mul(normal, rl_dot(local_pos, normal)));
         is.normal = rl_normalise(rl_sub(focal_point, plane_pr));
     } else if (surface_kind == RL_SURFACE_HEX_PRISM) {
-        is.normal = rl_xyz(sv.prisms[16 * group_index + 2 * hit.sub]); // SpacePartitioning: one-sided
+        is.normal = rl_xyz(sv.prisms[RL_PRISM_STRIDE * group_index + 2 * hit.sub]); // SpacePartitioning: one-sided
     } else { // plane, circle: two-sided
         const RlF3 n = rl_xyz(sv.planes[2 * group_index]);
         is.normal = (rl_dot(n, dir) < 0.0f) ? n : rl_neg(n);

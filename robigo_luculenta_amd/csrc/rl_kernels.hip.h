@@ -25,7 +25,7 @@
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
     uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cie, off_sphere_obj, total_f4;
-    uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects;
+    uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects, n_spheres_padded;
     RlCameraDesc camera;
     float screen_distance;
 };
@@ -39,6 +39,144 @@ struct RlTraceJob {
     uint64_t n_paths;
 };
 
+// Per-wave LDS scratch of the scan: the merge keys and the (prism, lane) work queue.
+struct RlWaveScratch {
+    unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
+    uint32_t queue[128];        // ring of (prism << 6) | owner lane
+};
+
+// One sphere test, geometry.rs:204-240 in the scaled form of rl_core.h.
+#define RL_SPHERE_TEST(S, INDEX)                                                                    \
+    {                                                                                               \
+        const float cox = (S).x - o.x, coy = (S).y - o.y, coz = (S).z - o.z;                        \
+        const float dd = dir.x * cox + dir.y * coy + dir.z * coz;                                   \
+        const float c = (cox * cox + coy * coy + coz * coz) - (S).w;                                \
+        const float q = dd * dd - c;                                                                \
+        if (q >= 0.0f && dd > 0.0f) {                                                               \
+            const float sq = sqrtf(q);                                                              \
+            const float t1 = dd - sq;                                                               \
+            const float t2 = dd + sq;                                                               \
+            if (t1 > 0.0f && t1 < t2 && t1 < best_t) {                                              \
+                best_t = t1;                                                                        \
+                slot = (INDEX);                                                                     \
+            }                                                                                       \
+        }                                                                                           \
+    }
+
+// Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
+// uniform control flow (`active` masks the lanes without a path): spheres, paraboloids, planes and
+// circles are tested lane-per-ray against wave-uniform records; hexagonal prisms -- ~600 instructions
+// per test, hit by a few lanes each -- are first culled per ray with their bounding sphere, the
+// surviving (prism, ray) pairs are compacted into a per-wave queue with __ballot, and the queue is
+// evaluated 64 pairs at a time with one pair per lane (rays fetched across lanes with ds_bpermute).
+// Results are min-merged per owning ray as 64-bit (distance, object) keys in LDS, which is the same
+// lexicographic "nearest, then first object" rule as rl_nearer().
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, bool active, RlWaveScratch* ws,
+                                              uint32_t lane, uint64_t lane_below) {
+    float best_t = 1.0e12f; // scene.rs:43
+    uint32_t slot = RL_HIT_NONE;
+    {
+        const RlF4* sph = sv.spheres;
+        RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
+        for (uint32_t i = 0; i < sv.n_spheres_padded; i += 4) {
+            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // prefetch (padded)
+            RL_SPHERE_TEST(c0, i)
+            RL_SPHERE_TEST(c1, i + 1)
+            RL_SPHERE_TEST(c2, i + 2)
+            RL_SPHERE_TEST(c3, i + 3)
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+    }
+    RlHit best;
+    best.t = best_t;
+    best.obj = RL_HIT_NONE;
+    best.sub = 0;
+    if (slot != RL_HIT_NONE) best.obj = sv.sphere_obj[slot];
+
+    for (uint32_t i = 0; i < sv.n_parabs; ++i) {
+        const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
+        const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
+        const uint32_t obj = rl_f2u(r0.w);
+        if (!(t < 0.0f) && rl_nearer(t, obj, best)) {
+            best.t = t;
+            best.obj = obj;
+        }
+    }
+    for (uint32_t i = 0; i < sv.n_planes; ++i) {
+        const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];
+        float dn;
+        const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
+        bool hit = t > 0.0f;
+        if (hit && r0.w >= 0.0f) {
+            const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
+            hit = rl_dot(dp, dp) <= r0.w;
+        }
+        const uint32_t obj = rl_f2u(r1.w);
+        if (hit && rl_nearer(t, obj, best)) {
+            best.t = t;
+            best.obj = obj;
+        }
+    }
+    if (sv.n_prisms == 0) return best;
+
+    // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
+    volatile unsigned long long* keys = ws->key;
+    volatile uint32_t* queue = ws->queue;
+    keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) | (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
+    uint32_t q_head = 0, q_tail = 0; // wave-uniform
+
+    auto process = [&](uint32_t count) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t e = queue[(q_head + lane) & 127u];
+        const uint32_t owner = e & 63u;
+        const uint32_t prism = e >> 6;
+        RlF3 ro, rd;
+        ro.x = __shfl(o.x, (int)owner);
+        ro.y = __shfl(o.y, (int)owner);
+        ro.z = __shfl(o.z, (int)owner);
+        rd.x = __shfl(dir.x, (int)owner);
+        rd.y = __shfl(dir.y, (int)owner);
+        rd.z = __shfl(dir.z, (int)owner);
+        if (lane < count) {
+            const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * prism;
+            const RlCand c = rl_hex_prism(pr, ro, rd);
+            if (c.t >= 0.0f) {
+                const uint32_t obj = rl_f2u(pr[1].w);
+                const unsigned long long k = ((unsigned long long)rl_f2u(c.t) << 32) | (unsigned long long)((obj << 3) | c.k);
+                atomicMin((unsigned long long*)&ws->key[owner], k);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (uint32_t i = 0; i < sv.n_prisms; ++i) {
+        const RlF4 b = sv.prisms[RL_PRISM_STRIDE * i + 16];
+        const bool pass = active && rl_prism_bound_pass(b, o, dir);
+        const uint64_t m = __ballot(pass);
+        if (m != 0) {
+            if (pass) queue[(q_tail + (uint32_t)__popcll(m & lane_below)) & 127u] = (i << 6) | lane;
+            q_tail += (uint32_t)__popcll(m);
+            if (q_tail - q_head >= 64u) {
+                process(64u);
+                q_head += 64u;
+            }
+        }
+    }
+    if (q_tail != q_head) process(q_tail - q_head);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long k = keys[lane];
+    const uint32_t low = (uint32_t)k;
+    best.t = rl_u2f((uint32_t)(k >> 32));
+    if (low == 0xffffffffu) {
+        best.obj = RL_HIT_NONE;
+        best.sub = 0;
+    } else {
+        best.obj = low >> 3;
+        best.sub = low & 7u;
+    }
+    return best;
+}
+
 // queue[0] = next unassigned path offset of this launch (zeroed before each launch),
 // queue[1] = cumulative segments, queue[2] = cumulative paths.
 template <bool STAGE_LDS>
@@ -47,6 +185,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
                                                             float* __restrict__ plot,
                                                             unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
+    __shared__ RlWaveScratch wave_scratch[RL_BLOCK / 64];
     const RlF4* base = scene;
     if (STAGE_LDS) {
         for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_BLOCK) smem[i] = scene[i];
@@ -62,6 +201,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
     sv.cie = base + lay.off_cie;
     sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
     sv.n_spheres = lay.n_spheres;
+    sv.n_spheres_padded = lay.n_spheres_padded;
     sv.n_planes = lay.n_planes;
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;
@@ -71,12 +211,20 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t lane_below = (1ull << lane) - 1ull;
+    RlWaveScratch* ws = &wave_scratch[threadIdx.x >> 6];
 
     uint64_t chunk_next = 0, chunk_end = 0; // wave-uniform
     bool drained = false;                   // wave-uniform
     bool active = false;
     uint64_t my_offset = 0;
     RlPath p;
+    p.origin = rl_f3(0.0f, 0.0f, 0.0f);
+    p.direction = rl_f3(0.0f, 0.0f, 1.0f);
+    p.wavelength = 0.0f;
+    p.intensity = 0.0f;
+    p.continue_chance = 0.0f;
+    p.sx = p.sy = 0.0f;
+    p.bounce = 0;
     uint32_t segments = 0, paths_done = 0;
 
     for (;;) {
@@ -109,8 +257,8 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
             if (chunk_next >= job.n_paths) drained = true;
         }
         if (__ballot(active) == 0) break;
+        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane, lane_below);
         if (active) {
-            const RlHit hit = rl_scan(sv, p.origin, p.direction);
             segments += 1;
             float value;
             if (rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value)) {

@@ -2,7 +2,9 @@
 // RlSceneDesc into the 16-byte records of rl_scene.h.  Pure host code (no device needed).
 #include "rl_scene.h"
 
+#include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "rl_core.h"
 
@@ -160,6 +162,58 @@ void push_infinite_prism(std::vector<RlF4>& recs, RlF3 axis, RlF3 offset, float 
     }
 }
 
+// Conservative bounding sphere of the convex polytope cut out by a prism's 8 half-spaces
+// (the 16 records at `pr`): vertices = triple-plane intersections inside all other planes, in f64.
+// The radius is inflated by 5 % + 1e-3 so float rounding in the hit position or in the cull test can
+// never reject a real hit; an unbounded or degenerate polytope gets an infinite radius (never culled).
+RlF4 prism_bound(const RlF4* pr) {
+    double n[8][3], d[8];
+    for (int k = 0; k < 8; ++k) {
+        n[k][0] = pr[2 * k].x; n[k][1] = pr[2 * k].y; n[k][2] = pr[2 * k].z;
+        d[k] = n[k][0] * pr[2 * k + 1].x + n[k][1] * pr[2 * k + 1].y + n[k][2] * pr[2 * k + 1].z; // n . offset
+    }
+    std::vector<double> vx, vy, vz;
+    bool unbounded = false;
+    for (int a = 0; a < 8; ++a)
+        for (int b = a + 1; b < 8; ++b)
+            for (int c = b + 1; c < 8; ++c) {
+                const double* A = n[a]; const double* B = n[b]; const double* Cc = n[c];
+                const double bxc[3] = {B[1] * Cc[2] - B[2] * Cc[1], B[2] * Cc[0] - B[0] * Cc[2], B[0] * Cc[1] - B[1] * Cc[0]};
+                const double cxa[3] = {Cc[1] * A[2] - Cc[2] * A[1], Cc[2] * A[0] - Cc[0] * A[2], Cc[0] * A[1] - Cc[1] * A[0]};
+                const double axb[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};
+                const double det = A[0] * bxc[0] + A[1] * bxc[1] + A[2] * bxc[2];
+                if (std::fabs(det) < 1e-9) continue;
+                double p[3];
+                for (int i = 0; i < 3; ++i) p[i] = (d[a] * bxc[i] + d[b] * cxa[i] + d[c] * axb[i]) / det;
+                bool inside = true;
+                for (int k = 0; k < 8 && inside; ++k)
+                    inside = (n[k][0] * p[0] + n[k][1] * p[1] + n[k][2] * p[2] - d[k]) <= 1e-6;
+                if (inside) {
+                    vx.push_back(p[0]); vy.push_back(p[1]); vz.push_back(p[2]);
+                }
+            }
+    RlF4 r;
+    r.x = r.y = r.z = 0.0f;
+    r.w = std::numeric_limits<float>::infinity();
+    if (vx.size() < 4) return r; // empty or degenerate: never cull
+    double c[3] = {0, 0, 0};
+    for (size_t i = 0; i < vx.size(); ++i) { c[0] += vx[i]; c[1] += vy[i]; c[2] += vz[i]; }
+    for (int i = 0; i < 3; ++i) c[i] /= (double)vx.size();
+    // The polytope is bounded iff every direction is blocked; with the reference's constructors it
+    // always is.  Guard anyway: a vertex farther than 1e6 means "treat as unbounded".
+    double r2 = 0;
+    for (size_t i = 0; i < vx.size(); ++i) {
+        const double dx = vx[i] - c[0], dy = vy[i] - c[1], dz = vz[i] - c[2];
+        r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+    }
+    if (!(r2 < 1e12)) unbounded = true;
+    if (unbounded) return r;
+    const double radius = std::sqrt(r2) * 1.05 + 1e-3;
+    r.x = (float)c[0]; r.y = (float)c[1]; r.z = (float)c[2];
+    r.w = (float)(radius * radius);
+    return r;
+}
+
 } // namespace
 
 uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, RlCameraDesc* camera) {
@@ -208,7 +262,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
             break;
         }
         case RL_SURFACE_HEX_PRISM: { // geometry.rs:493-515
-            group_index = (uint32_t)(fs.prisms.size() / 16);
+            group_index = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
             const RlF3 axis = F(o.v0), offset = F(o.v1);
             const float edge_length = o.f0, bevel_size = o.f1, angle = o.f2, height = o.f3;
             push_infinite_prism(fs.prisms, axis, offset, edge_length * 2.0f - bevel_size * 3.0f, angle + PI, objbits);
@@ -217,6 +271,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
             fs.prisms.push_back(F4(offset, objbits));
             fs.prisms.push_back(F4(axis, 0.0f));
             fs.prisms.push_back(F4(rl_add(offset, rl_mul(axis, height)), objbits));
+            fs.prisms.push_back(prism_bound(&fs.prisms[fs.prisms.size() - 16]));
             break;
         }
         default:
@@ -236,5 +291,12 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         fs.objects.push_back(a);
         fs.objects.push_back(b);
     }
+    // Dummy spheres that can never be hit: c = |co|^2 - (-inf) = +inf, q = -inf < 0.
+    fs.n_spheres = (uint32_t)fs.spheres.size();
+    fs.n_spheres_padded = (fs.n_spheres + 3u) & ~3u;
+    RlF4 dummy;
+    dummy.x = dummy.y = dummy.z = 0.0f;
+    dummy.w = -std::numeric_limits<float>::infinity();
+    fs.spheres.resize(fs.n_spheres_padded + 4, dummy);
     return RL_OK;
 }

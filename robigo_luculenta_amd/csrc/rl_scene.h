@@ -8,9 +8,15 @@
 //   spheres   1 x RlF4 each : {centre.xyz, radius^2}                         geometry.rs:186-200
 //   planes    2 x RlF4 each : {normal.xyz, radius^2 or -1}, {offset.xyz, obj} geometry.rs:35-51,130-150
 //   parabs    3 x RlF4 each : {offset.xyz, obj}, {normal.xyz, 0}, {focal_point.xyz, 0}   :269-295
-//   prisms   16 x RlF4 each : 8 half-spaces x ({normal.xyz, 0}, {offset.xyz, obj})       :409-515
+//   prisms   17 x RlF4 each : 8 half-spaces x ({normal.xyz, 0}, {offset.xyz, obj})       :409-515
+//                             + {bounding-sphere centre.xyz, radius^2} (not in the reference: a
+//                             conservative cull, see rl_prism_bound_pass); the odd stride also keeps
+//                             per-lane prism fetches off a single LDS bank row
 //   objects   2 x RlF4 each : {surface_kind | material_kind << 8, group index, 0, 0} as bits,
 //                             {m0, m1, m2, 0}  (black body: m0 = kelvins, m1 = normalisation factor)
+//
+// The sphere array is padded with never-hit dummies (radius^2 = -inf) to a multiple of 4 plus one
+// extra group of 4, so the kernel can unroll by 4 and prefetch one group ahead without a bounds check.
 //
 // Spheres are scanned first with the reference's strict `<`; the other groups are merged with the
 // lexicographic (distance, object index) rule, which is exactly scene.rs:51's "first object wins".
@@ -25,6 +31,8 @@ struct alignas(16) RlF4 {
     float x, y, z, w;
 };
 
+#define RL_PRISM_STRIDE 17 // records per hexagonal prism: 16 half-space records + 1 bound
+
 // Everything the per-path code needs to read; pointers are device or host memory depending on
 // who built the view.
 struct RlSceneView {
@@ -36,6 +44,7 @@ struct RlSceneView {
     const uint32_t* sphere_obj;
     const RlF4* cie; // RL_CIE_SAMPLES rows {X, Y, Z, 0}
     uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects;
+    uint32_t n_spheres_padded; // multiple of 4; records [n_spheres, n_spheres_padded + 4) are dummies
     RlCameraDesc camera;
     float screen_distance; // 1 / tan(field_of_view / 2), camera.rs:56 (constant per scene)
 };
@@ -44,6 +53,8 @@ struct RlSceneView {
 struct RlFlatScene {
     std::vector<RlF4> spheres, planes, parabs, prisms, objects;
     std::vector<uint32_t> sphere_obj;
+    uint32_t n_spheres;        // real spheres; `spheres` also holds the dummy padding
+    uint32_t n_spheres_padded; // see RlSceneView
     RlCameraDesc camera;
     float screen_distance;
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).

@@ -35,10 +35,11 @@ void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDe
     v.objects = m->flat.objects.data();
     v.sphere_obj = m->flat.sphere_obj.data();
     v.cie = (const RlF4*)RL_CIE1931_XYZ0;
-    v.n_spheres = (uint32_t)m->flat.spheres.size();
+    v.n_spheres = m->flat.n_spheres;
+    v.n_spheres_padded = m->flat.n_spheres_padded;
     v.n_planes = (uint32_t)(m->flat.planes.size() / 2);
     v.n_parabs = (uint32_t)(m->flat.parabs.size() / 3);
-    v.n_prisms = (uint32_t)(m->flat.prisms.size() / 16);
+    v.n_prisms = (uint32_t)(m->flat.prisms.size() / RL_PRISM_STRIDE);
     v.n_objects = (uint32_t)(m->flat.objects.size() / 2);
     v.camera = m->flat.camera;
     v.screen_distance = m->flat.screen_distance;
