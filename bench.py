@@ -33,6 +33,10 @@ CONFIGS = {
     "demo-720p": ("demo", 0, 1280, 720),        # configs[1]
     "glass-720p": ("glass", 0, 1280, 720),      # configs[2]
     "replicated-1080p": ("demo", 158, 1920, 1080),  # configs[4]
+    # ablation scenes (not BASELINE configs): prefixes of the demo scene's object list
+    "ablate-noprisms": ("demo[:317]", 0, 1920, 1080),
+    "ablate-fixed7": ("demo[:7]", 0, 1920, 1080),
+    "ablate-seeds": ("demo[:207]", 0, 1920, 1080),
 }
 
 
@@ -114,8 +118,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
     scene_name, param, W, H = CONFIGS[args.config]
-    which = R.SCENE_DEMO if scene_name == "demo" else R.SCENE_GLASS_STRESS
+    which = R.SCENE_DEMO if scene_name.startswith("demo") else R.SCENE_GLASS_STRESS
     objs, cam = R.builtin_scene_desc(which, param)
+    if "[:" in scene_name:
+        objs = objs[: int(scene_name.split("[:")[1].rstrip("]"))].copy()
     scene = R.Scene(objs, cam, device=device)
     trace = R.TraceUnit(rank, W, H, n_photons=64, device=device)  # fused mode does not use mapped_photons
     trace.set_fetch(R.FETCH_LDS if args.fetch == "lds" else R.FETCH_GLOBAL)

@@ -39,44 +39,95 @@ struct RlTraceJob {
     uint64_t n_paths;
 };
 
+typedef __attribute__((address_space(3))) unsigned long long RlLdsU64;
+typedef __attribute__((address_space(3))) uint32_t RlLdsU32;
+
+// All LDS traffic of the scan stays inside one wave, whose DS instructions execute in order; this
+// only has to stop the compiler from moving or caching LDS accesses across the hand-over points.
+__device__ __forceinline__ void rl_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Number of set bits of `mask` below this lane (v_mbcnt_lo/hi).
+__device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Per-wave LDS scratch of the scan: the merge keys and the (prism, lane) work queue.
 struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t queue[128];        // ring of (prism << 6) | owner lane
 };
 
-// One sphere test, geometry.rs:204-240 in the scaled form of rl_core.h.
+// Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
+// uniform control flow (`active` masks the lanes without a path).
+//
+// Every primitive group is scanned lane-per-ray against wave-uniform records, but only up to the
+// cheap, exact reject test; the rare expensive tails are not executed under divergence.  Instead the
+// (primitive, ray) pairs that survive are compacted with __ballot into a per-wave LDS ring and
+// evaluated 64 pairs at a time, one pair per lane, with the ray fetched across lanes (ds_bpermute):
+//   * spheres: the reject test is the discriminant sign (q >= 0 and d.co > 0, 16 flops + 2 compares,
+//     geometry.rs:204-216 in the scaled form of rl_core.h); survivors (~0.5 per ray) take the
+//     IEEE sqrt / root-selection tail (geometry.rs:217-240) in the compacted round;
+//   * hexagonal prisms (~600 instructions per test): culled per ray with a conservative bounding
+//     sphere, survivors evaluated in compacted rounds.
+// Results are min-merged per owning ray as 64-bit (distance bits, index) keys in LDS -- the same
+// "nearest, then first in scan order" rule as scene.rs:51 / rl_nearer().
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, bool active, RlWaveScratch* ws,
+                                              uint32_t lane, uint64_t lane_below) {
+    // Explicit LDS address space: generic pointers here would become flat_* accesses.
+    RlLdsU64* keys = (RlLdsU64*)ws->key;
+    RlLdsU32* queue = (RlLdsU32*)ws->queue;
+    uint32_t q_head = 0, q_tail = 0; // wave-uniform ring indices
+    const RlF4* sph = sv.spheres;
+
+    keys[lane] = ((unsigned long long)rl_f2u(1.0e12f) << 32) | 0xffffffffull; // scene.rs:43
+
+    auto process_spheres = [&](uint32_t count) {
+        rl_wave_sync();
+        const uint32_t e = queue[(q_head + lane) & 127u];
+        const uint32_t owner = e & 63u;
+        const uint32_t slot = e >> 6;
+        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
+        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
+        if (lane < count) {
+            const RlF4 s = sph[slot];
+            const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
+            const float dd = dx * cox + dy * coy + dz * coz;
+            const float c = (cox * cox + coy * coy + coz * coz) - s.w;
+            const float q = dd * dd - c;
+            const float sq = sqrtf(q);
+            const float t1 = dd - sq;
+            const float t2 = dd + sq;
+            if (t1 > 0.0f && t1 < t2)
+                __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)slot,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        rl_wave_sync();
+    };
+
 #define RL_SPHERE_TEST(S, INDEX)                                                                    \
     {                                                                                               \
         const float cox = (S).x - o.x, coy = (S).y - o.y, coz = (S).z - o.z;                        \
         const float dd = dir.x * cox + dir.y * coy + dir.z * coz;                                   \
         const float c = (cox * cox + coy * coy + coz * coz) - (S).w;                                \
         const float q = dd * dd - c;                                                                \
-        if (q >= 0.0f && dd > 0.0f) {                                                               \
-            const float sq = sqrtf(q);                                                              \
-            const float t1 = dd - sq;                                                               \
-            const float t2 = dd + sq;                                                               \
-            if (t1 > 0.0f && t1 < t2 && t1 < best_t) {                                              \
-                best_t = t1;                                                                        \
-                slot = (INDEX);                                                                     \
+        /* superset of (q >= 0 && d.co > 0) as ONE integer compare on the sign bits; the compacted */ \
+        /* round re-evaluates the exact float conditions.  Lanes without a path carry dir = 0.     */ \
+        const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u)) >= 0;                                \
+        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
+        if (m != 0) {                                                                               \
+            if (cand) queue[(q_tail + rl_mbcnt(m)) & 127u] = ((INDEX) << 6) | lane;                 \
+            q_tail += (uint32_t)__popcll(m);                                                        \
+            if (q_tail - q_head >= 64u) {                                                           \
+                process_spheres(64u);                                                               \
+                q_head += 64u;                                                                      \
             }                                                                                       \
         }                                                                                           \
     }
 
-// Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
-// uniform control flow (`active` masks the lanes without a path): spheres, paraboloids, planes and
-// circles are tested lane-per-ray against wave-uniform records; hexagonal prisms -- ~600 instructions
-// per test, hit by a few lanes each -- are first culled per ray with their bounding sphere, the
-// surviving (prism, ray) pairs are compacted into a per-wave queue with __ballot, and the queue is
-// evaluated 64 pairs at a time with one pair per lane (rays fetched across lanes with ds_bpermute).
-// Results are min-merged per owning ray as 64-bit (distance, object) keys in LDS, which is the same
-// lexicographic "nearest, then first object" rule as rl_nearer().
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, bool active, RlWaveScratch* ws,
-                                              uint32_t lane, uint64_t lane_below) {
-    float best_t = 1.0e12f; // scene.rs:43
-    uint32_t slot = RL_HIT_NONE;
     {
-        const RlF4* sph = sv.spheres;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
         for (uint32_t i = 0; i < sv.n_spheres_padded; i += 4) {
             const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // prefetch (padded)
@@ -87,6 +138,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
     }
+#undef RL_SPHERE_TEST
+    if (q_tail != q_head) process_spheres(q_tail - q_head);
+    q_head = q_tail;
+    rl_wave_sync();
+    const unsigned long long ks = keys[lane];
+    const float best_t = rl_u2f((uint32_t)(ks >> 32));
+    const uint32_t slot = (uint32_t)ks;
+
     RlHit best;
     best.t = best_t;
     best.obj = RL_HIT_NONE;
@@ -120,13 +179,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
     if (sv.n_prisms == 0) return best;
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
-    volatile unsigned long long* keys = ws->key;
-    volatile uint32_t* queue = ws->queue;
+    rl_wave_sync();
     keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) | (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
-    uint32_t q_head = 0, q_tail = 0; // wave-uniform
-
     auto process = [&](uint32_t count) {
-        __builtin_amdgcn_wave_barrier();
+        rl_wave_sync();
         const uint32_t e = queue[(q_head + lane) & 127u];
         const uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
@@ -143,18 +199,18 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
             if (c.t >= 0.0f) {
                 const uint32_t obj = rl_f2u(pr[1].w);
                 const unsigned long long k = ((unsigned long long)rl_f2u(c.t) << 32) | (unsigned long long)((obj << 3) | c.k);
-                atomicMin((unsigned long long*)&ws->key[owner], k);
+                __hip_atomic_fetch_min(keys + owner, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        rl_wave_sync();
     };
 
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4 b = sv.prisms[RL_PRISM_STRIDE * i + 16];
         const bool pass = active && rl_prism_bound_pass(b, o, dir);
-        const uint64_t m = __ballot(pass);
+        const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
-            if (pass) queue[(q_tail + (uint32_t)__popcll(m & lane_below)) & 127u] = (i << 6) | lane;
+            if (pass) queue[(q_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
             q_tail += (uint32_t)__popcll(m);
             if (q_tail - q_head >= 64u) {
                 process(64u);
@@ -163,7 +219,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }
     }
     if (q_tail != q_head) process(q_tail - q_head);
-    __builtin_amdgcn_wave_barrier();
+    rl_wave_sync();
     const unsigned long long k = keys[lane];
     const uint32_t low = (uint32_t)k;
     best.t = rl_u2f((uint32_t)(k >> 32));
@@ -180,7 +236,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
 // queue[0] = next unassigned path offset of this launch (zeroed before each launch),
 // queue[1] = cumulative segments, queue[2] = cumulative paths.
 template <bool STAGE_LDS>
-__global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
+__global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                             RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                             float* __restrict__ plot,
                                                             unsigned long long* __restrict__ queue) {
@@ -219,7 +275,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
     uint64_t my_offset = 0;
     RlPath p;
     p.origin = rl_f3(0.0f, 0.0f, 0.0f);
-    p.direction = rl_f3(0.0f, 0.0f, 1.0f);
+    p.direction = rl_f3(0.0f, 0.0f, 0.0f); // a lane without a path scans with d = 0: never a sphere candidate
     p.wavelength = 0.0f;
     p.intensity = 0.0f;
     p.continue_chance = 0.0f;
@@ -228,10 +284,10 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
     uint32_t segments = 0, paths_done = 0;
 
     for (;;) {
-        const uint64_t need = __ballot(!active);
+        const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
         if (need != 0 && !drained) {
             const uint32_t cnt = (uint32_t)__popcll(need);
-            const uint32_t rank = (uint32_t)__popcll(need & lane_below);
+            const uint32_t rank = rl_mbcnt(need);
             const uint64_t avail = chunk_end - chunk_next;
             const uint64_t base0 = chunk_next;
             uint64_t base1 = 0;
@@ -256,13 +312,14 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_trace_kernel(const RlF4* __restri
             }
             if (chunk_next >= job.n_paths) drained = true;
         }
-        if (__ballot(active) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane, lane_below);
         if (active) {
             segments += 1;
             float value;
             if (rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value)) {
                 active = false;
+                p.direction = rl_f3(0.0f, 0.0f, 0.0f);
                 paths_done += 1;
                 if (photons) {
                     RlMappedPhoton ph;

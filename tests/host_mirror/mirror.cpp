@@ -93,3 +93,28 @@ void mirror_plot(RlVector3* buffer, uint32_t w, uint32_t h, const RlMappedPhoton
     }
 }
 }
+
+// Dumps the rays (origin, direction) of every segment of paths [first, first+n): analysis helper for
+// sizing the kernel's culling structures.  Returns the number of rays written (<= cap).
+extern "C" uint64_t mirror_dump_rays(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first,
+                                     uint64_t n, float* rays6, uint64_t cap) {
+    const RlSceneView& sv = ((MirrorScene*)scene)->view;
+    const float aspect = (float)w / (float)h;
+    uint64_t count = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        RlPath p;
+        rl_begin_path(sv, aspect, seed, stream, first + i, &p);
+        float value = 0.0f;
+        for (;;) {
+            if (count < cap) {
+                float* r = rays6 + 6 * count;
+                r[0] = p.origin.x; r[1] = p.origin.y; r[2] = p.origin.z;
+                r[3] = p.direction.x; r[4] = p.direction.y; r[5] = p.direction.z;
+                count++;
+            }
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value)) break;
+        }
+    }
+    return count;
+}

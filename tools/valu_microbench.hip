@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void mb(float* out, float a, float b) {
             if (MODE == 11) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(*(double*)&p[i]) : "v"(*(double*)&p[(i + 1) % UNROLL]), "v"(*(double*)&p[(i + 2) % UNROLL]));
             if (MODE == 12) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
             if (MODE == 13) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (MODE == 14) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[10:11]" : "+v"(x[i]) : "v"(a) : "s10", "s11");
+            if (MODE == 15) asm volatile("v_cmp_lt_f32_e64 s[10:11], %0, %1" : : "v"(x[i]), "v"(a) : "s10", "s11");
+            if (MODE == 16) asm volatile("v_mov_b32 %0, %1" : "+v"(x[i]) : "v"(a));
+            if (MODE == 17) asm volatile("v_min_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (MODE == 18) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a) : "vcc");
+            if (MODE == 19) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\ts_and_saveexec_b64 s[10:11], vcc\n\tv_mov_b32 %0, %1\n\ts_mov_b64 exec, s[10:11]" : "+v"(x[i]) : "v"(a) : "vcc", "s10", "s11");
+            if (MODE == 20) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (MODE == 21) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (MODE == 22) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[i]) : "v"(a), "v"(b) : "vcc");
+            if (MODE == 23) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "s"(b));
+            if (MODE == 24) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
         }
     }
     float s = 0;
@@ -68,7 +79,7 @@ void run(const char* name, float flops_per_lane_inst, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4}) {
         run<0>("v_fma_f32", 2, w);
         run<1>("v_mul_f32", 1, w);
         run<2>("v_add_f32", 1, w);
@@ -83,6 +94,17 @@ int main() {
         run<11>("v_fma_f64", 2, w);
         run<12>("v_mul_lo_u32", 1, w);
         run<13>("v_mul_hi_u32", 1, w);
+        run<14>("cndmask e64 sgpr", 1, w);
+        run<15>("v_cmp e64 sgpr", 1, w);
+        run<16>("v_mov_b32", 1, w);
+        run<17>("v_min_f32", 1, w);
+        run<18>("cmp+cndmask", 1, w);
+        run<19>("cmp+saveexec+mov", 1, w);
+        run<20>("v_add_u32", 1, w);
+        run<21>("v_and_b32", 1, w);
+        run<22>("cndmask 3reg", 1, w);
+        run<23>("v_sub_f32 s-arg", 1, w);
+        run<24>("v_fma acc", 2, w);
     }
     return 0;
 }
