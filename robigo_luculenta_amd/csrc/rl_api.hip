@@ -224,8 +224,10 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     blob.resize(blob.size() + so_f4);
     std::memcpy(blob.data() + lay.off_sphere_obj, fs.sphere_obj.data(), fs.sphere_obj.size() * sizeof(uint32_t));
     lay.total_f4 = (uint32_t)blob.size();
-    lay.n_spheres = fs.n_spheres;
-    lay.n_spheres_padded = fs.n_spheres_padded;
+    lay.n_direct = fs.n_direct;
+    lay.n_direct_padded = fs.n_direct_padded;
+    lay.cluster_base = fs.cluster_base;
+    lay.n_clusters = fs.n_clusters;
     lay.n_planes = (uint32_t)(fs.planes.size() / 2);
     lay.n_parabs = (uint32_t)(fs.parabs.size() / 3);
     lay.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);

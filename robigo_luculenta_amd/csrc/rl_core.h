@@ -247,10 +247,10 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     return rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
 }
 
-// Conservative cull for a hexagonal prism (not in the reference): a valid hit lies on the prism's
-// surface, hence inside its bounding sphere `b` = {centre, radius^2} (radius inflated by 5 %, see
+// Conservative cull (not in the reference) for a hexagonal prism or a sphere cluster: a valid hit
+// lies inside the bounding sphere `b` = {centre, radius^2} (radius inflated by >= 5 %, see
 // rl_scene.cpp).  Returns false only when the ray certainly misses the sphere in front of its origin.
-RL_HD bool rl_prism_bound_pass(RlF4 b, RlF3 o, RlF3 dir) {
+RL_HD bool rl_bound_pass(RlF4 b, RlF3 o, RlF3 dir) {
     const float cox = b.x - o.x, coy = b.y - o.y, coz = b.z - o.z;
     const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
     const float c = (cox * cox + coy * coy + coz * coz) - b.w;
@@ -269,10 +269,9 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
     best.obj = RL_HIT_NONE;
     best.sub = 0;
 
-    // Spheres (geometry.rs:204-240).  `slot` is translated to the object index after the loop.
-    uint32_t slot = RL_HIT_NONE;
-    for (uint32_t i = 0; i < sv.n_spheres; ++i) {
-        const RlF4 s = sv.spheres[i];
+    // Spheres (geometry.rs:204-240): the direct list, then the clusters whose bound the ray reaches.
+    auto sphere_test = [&](uint32_t pos) {
+        const RlF4 s = sv.spheres[pos];
         const float cox = s.x - o.x, coy = s.y - o.y, coz = s.z - o.z;
         const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
         const float c = (cox * cox + coy * coy + coz * coz) - s.w;
@@ -281,13 +280,19 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
             const float sq = sqrtf(q);
             const float t1 = dd - sq;
             const float t2 = dd + sq;
-            if (t1 > 0.0f && t1 < t2 && t1 < best.t) {
+            const uint32_t obj = sv.sphere_obj[pos];
+            if (t1 > 0.0f && t1 < t2 && rl_nearer(t1, obj, best)) {
                 best.t = t1;
-                slot = i;
+                best.obj = obj;
             }
         }
+    };
+    for (uint32_t i = 0; i < sv.n_direct; ++i) sphere_test(i);
+    for (uint32_t k = 0; k < sv.n_clusters; ++k) {
+        const uint32_t base = sv.cluster_base + RL_CLUSTER_STRIDE * k;
+        if (!rl_bound_pass(sv.spheres[base], o, dir)) continue;
+        for (uint32_t j = 1; j <= RL_CLUSTER_K; ++j) sphere_test(base + j);
     }
-    if (slot != RL_HIT_NONE) best.obj = sv.sphere_obj[slot];
 
     // Paraboloids.
     for (uint32_t i = 0; i < sv.n_parabs; ++i) {
@@ -318,7 +323,7 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
     // Hexagonal prisms.
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * i;
-        if (!rl_prism_bound_pass(pr[16], o, dir)) continue;
+        if (!rl_bound_pass(pr[16], o, dir)) continue;
         const RlCand c = rl_hex_prism(pr, o, dir);
         const uint32_t obj = rl_f2u(pr[1].w);
         if (c.t >= 0.0f && rl_nearer(c.t, obj, best)) {

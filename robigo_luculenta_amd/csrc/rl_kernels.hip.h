@@ -25,7 +25,7 @@
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
     uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cie, off_sphere_obj, total_f4;
-    uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects, n_spheres_padded;
+    uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
     RlCameraDesc camera;
     float screen_distance;
 };
@@ -54,104 +54,43 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// Per-wave LDS scratch of the scan: the merge keys and the (prism, lane) work queue.
+// Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
 struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
-    uint32_t queue[128];        // ring of (prism << 6) | owner lane
+    uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
+    uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
 };
 
 // Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
-// uniform control flow (`active` masks the lanes without a path).
+// uniform control flow (`active` masks the lanes without a path; such lanes carry dir = 0).
 //
-// Every primitive group is scanned lane-per-ray against wave-uniform records, but only up to the
-// cheap, exact reject test; the rare expensive tails are not executed under divergence.  Instead the
-// (primitive, ray) pairs that survive are compacted with __ballot into a per-wave LDS ring and
-// evaluated 64 pairs at a time, one pair per lane, with the ray fetched across lanes (ds_bpermute):
-//   * spheres: the reject test is the discriminant sign (q >= 0 and d.co > 0, 16 flops + 2 compares,
-//     geometry.rs:204-216 in the scaled form of rl_core.h); survivors (~0.5 per ray) take the
-//     IEEE sqrt / root-selection tail (geometry.rs:217-240) in the compacted round;
-//   * hexagonal prisms (~600 instructions per test): culled per ray with a conservative bounding
-//     sphere, survivors evaluated in compacted rounds.
-// Results are min-merged per owning ray as 64-bit (distance bits, index) keys in LDS -- the same
-// "nearest, then first in scan order" rule as scene.rs:51 / rl_nearer().
+// Every ray is tested against wave-uniform records (LDS broadcast or scalar loads) only up to a cheap
+// reject test; expensive tails never run under divergence.  The (item, ray) pairs that survive are
+// compacted with ballot/mbcnt into per-wave LDS rings and evaluated 64 pairs at a time, one pair per
+// lane, with the ray fetched across lanes (ds_bpermute):
+//   * direct spheres: reject = sign bits of the discriminant q and of d.co (16 flops + 3 int ops,
+//     geometry.rs:204-216 in the scaled form of rl_core.h) -> ring B;
+//   * sphere clusters (rl_scene.h): reject = conservative bounding-sphere test -> ring A; a ring-A
+//     round runs the same reject test of the cluster's RL_CLUSTER_K members -> ring B;
+//   * ring B rounds: exact IEEE sqrt / root selection (geometry.rs:217-240), then min-merge;
+//   * hexagonal prisms (~600 instructions per test): conservative bounding-sphere test -> ring A,
+//     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
+// Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
+// scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, bool active, RlWaveScratch* ws,
-                                              uint32_t lane, uint64_t lane_below) {
+                                              uint32_t lane) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
-    RlLdsU32* queue = (RlLdsU32*)ws->queue;
-    uint32_t q_head = 0, q_tail = 0; // wave-uniform ring indices
+    RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
+    RlLdsU32* ring_b = (RlLdsU32*)ws->ring_b;
+    uint32_t a_head = 0, a_tail = 0, b_head = 0, b_tail = 0; // wave-uniform ring indices
     const RlF4* sph = sv.spheres;
 
-    keys[lane] = ((unsigned long long)rl_f2u(1.0e12f) << 32) | 0xffffffffull; // scene.rs:43
-
-    auto process_spheres = [&](uint32_t count) {
-        rl_wave_sync();
-        const uint32_t e = queue[(q_head + lane) & 127u];
-        const uint32_t owner = e & 63u;
-        const uint32_t slot = e >> 6;
-        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
-        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
-        if (lane < count) {
-            const RlF4 s = sph[slot];
-            const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
-            const float dd = dx * cox + dy * coy + dz * coz;
-            const float c = (cox * cox + coy * coy + coz * coz) - s.w;
-            const float q = dd * dd - c;
-            const float sq = sqrtf(q);
-            const float t1 = dd - sq;
-            const float t2 = dd + sq;
-            if (t1 > 0.0f && t1 < t2)
-                __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)slot,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        rl_wave_sync();
-    };
-
-#define RL_SPHERE_TEST(S, INDEX)                                                                    \
-    {                                                                                               \
-        const float cox = (S).x - o.x, coy = (S).y - o.y, coz = (S).z - o.z;                        \
-        const float dd = dir.x * cox + dir.y * coy + dir.z * coz;                                   \
-        const float c = (cox * cox + coy * coy + coz * coz) - (S).w;                                \
-        const float q = dd * dd - c;                                                                \
-        /* superset of (q >= 0 && d.co > 0) as ONE integer compare on the sign bits; the compacted */ \
-        /* round re-evaluates the exact float conditions.  Lanes without a path carry dir = 0.     */ \
-        const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u)) >= 0;                                \
-        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
-        if (m != 0) {                                                                               \
-            if (cand) queue[(q_tail + rl_mbcnt(m)) & 127u] = ((INDEX) << 6) | lane;                 \
-            q_tail += (uint32_t)__popcll(m);                                                        \
-            if (q_tail - q_head >= 64u) {                                                           \
-                process_spheres(64u);                                                               \
-                q_head += 64u;                                                                      \
-            }                                                                                       \
-        }                                                                                           \
-    }
-
-    {
-        RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
-        for (uint32_t i = 0; i < sv.n_spheres_padded; i += 4) {
-            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // prefetch (padded)
-            RL_SPHERE_TEST(c0, i)
-            RL_SPHERE_TEST(c1, i + 1)
-            RL_SPHERE_TEST(c2, i + 2)
-            RL_SPHERE_TEST(c3, i + 3)
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        }
-    }
-#undef RL_SPHERE_TEST
-    if (q_tail != q_head) process_spheres(q_tail - q_head);
-    q_head = q_tail;
-    rl_wave_sync();
-    const unsigned long long ks = keys[lane];
-    const float best_t = rl_u2f((uint32_t)(ks >> 32));
-    const uint32_t slot = (uint32_t)ks;
-
+    // Paraboloids, planes and circles: a handful of records, evaluated in registers.
     RlHit best;
-    best.t = best_t;
+    best.t = 1.0e12f; // scene.rs:43
     best.obj = RL_HIT_NONE;
     best.sub = 0;
-    if (slot != RL_HIT_NONE) best.obj = sv.sphere_obj[slot];
-
     for (uint32_t i = 0; i < sv.n_parabs; ++i) {
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
@@ -176,14 +115,122 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
             best.obj = obj;
         }
     }
-    if (sv.n_prisms == 0) return best;
+    keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) |
+                 (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
+
+    // ---- ring B round: exact sphere tail for (record position, owner) pairs ----
+    auto process_spheres = [&](uint32_t count) {
+        rl_wave_sync();
+        const uint32_t e = ring_b[(b_head + lane) & 127u];
+        const uint32_t owner = e & 63u;
+        const uint32_t pos = e >> 6;
+        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
+        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
+        if (lane < count) {
+            const RlF4 s = sph[pos];
+            const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
+            const float dd = dx * cox + dy * coy + dz * coz;
+            const float c = (cox * cox + coy * coy + coz * coz) - s.w;
+            const float q = dd * dd - c;
+            const float sq = sqrtf(q);
+            const float t1 = dd - sq;
+            const float t2 = dd + sq;
+            if (t1 > 0.0f && t1 < t2) {
+                const uint32_t obj = sv.sphere_obj[pos];
+                __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)(obj << 3),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+        rl_wave_sync();
+    };
+
+    // Reject test of one sphere record S for the ray (OX.., DX..); survivors go to ring B as
+    // (POS << 6) | OWNER.  The integer compare is a superset of (q >= 0 && d.co > 0) on the sign
+    // bits; the ring-B round re-evaluates the exact float conditions.
+#define RL_SPHERE_REJECT(S, POS, OWNER, ENABLE, OX, OY, OZ, DX, DY, DZ)                             \
+    {                                                                                               \
+        const float cox = (S).x - (OX), coy = (S).y - (OY), coz = (S).z - (OZ);                     \
+        const float dd = (DX) * cox + (DY) * coy + (DZ) * coz;                                      \
+        const float c = (cox * cox + coy * coy + coz * coz) - (S).w;                                \
+        const float q = dd * dd - c;                                                                \
+        const bool cand = ENABLE((int)(rl_f2u(q) | (rl_f2u(dd) - 1u)) >= 0);                        \
+        const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
+        if (m != 0) {                                                                               \
+            if (cand) ring_b[(b_tail + rl_mbcnt(m)) & 127u] = ((POS) << 6) | (OWNER);               \
+            b_tail += (uint32_t)__popcll(m);                                                        \
+            if (b_tail - b_head >= 64u) {                                                           \
+                process_spheres(64u);                                                               \
+                b_head += 64u;                                                                      \
+            }                                                                                       \
+        }                                                                                           \
+    }
+#define RL_ALWAYS(X) (X)
+
+    // ---- direct spheres: every ray against every record, unrolled by 4 with one group of prefetch ----
+    if (sv.n_direct != 0) {
+        RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
+        for (uint32_t i = 0; i < sv.n_direct_padded; i += 4) {
+            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // padded
+            RL_SPHERE_REJECT(c0, i, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c1, i + 1, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c2, i + 2, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c3, i + 3, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+    }
+
+    // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members ----
+    auto process_clusters = [&](uint32_t count) {
+        rl_wave_sync();
+        const uint32_t e = ring_a[(a_head + lane) & 127u];
+        const uint32_t owner = e & 63u;
+        const uint32_t first = sv.cluster_base + RL_CLUSTER_STRIDE * (e >> 6) + 1u;
+        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
+        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
+        const bool mine = lane < count;
+#define RL_IF_MINE(X) (mine && (X))
+#pragma unroll 2
+        for (uint32_t j = 0; j < RL_CLUSTER_K; ++j) {
+            const RlF4 s = sph[first + j];
+            RL_SPHERE_REJECT(s, first + j, owner, RL_IF_MINE, ox, oy, oz, dx, dy, dz)
+        }
+#undef RL_IF_MINE
+        rl_wave_sync();
+    };
+
+    // ---- sphere clusters: bound cull per ray -> ring A ----
+    if (sv.n_clusters != 0) {
+        const uint32_t last = sv.cluster_base + RL_CLUSTER_STRIDE * (sv.n_clusters - 1u);
+        uint32_t at = sv.cluster_base;
+        RlF4 b = sph[at];
+        for (uint32_t k = 0; k < sv.n_clusters; ++k) {
+            const uint32_t next = at + RL_CLUSTER_STRIDE;
+            const RlF4 nb = sph[next <= last ? next : last]; // prefetch the next bound
+            const bool pass = active && rl_bound_pass(b, o, dir);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
+            if (m != 0) {
+                if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (k << 6) | lane;
+                a_tail += (uint32_t)__popcll(m);
+                if (a_tail - a_head >= 64u) {
+                    process_clusters(64u);
+                    a_head += 64u;
+                }
+            }
+            at = next;
+            b = nb;
+        }
+        if (a_tail != a_head) process_clusters(a_tail - a_head);
+        a_head = a_tail;
+    }
+#undef RL_SPHERE_REJECT
+#undef RL_ALWAYS
+    if (b_tail != b_head) process_spheres(b_tail - b_head);
+    b_head = b_tail;
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
-    rl_wave_sync();
-    keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) | (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
-    auto process = [&](uint32_t count) {
+    auto process_prisms = [&](uint32_t count) {
         rl_wave_sync();
-        const uint32_t e = queue[(q_head + lane) & 127u];
+        const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
         RlF3 ro, rd;
@@ -204,21 +251,21 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }
         rl_wave_sync();
     };
-
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4 b = sv.prisms[RL_PRISM_STRIDE * i + 16];
-        const bool pass = active && rl_prism_bound_pass(b, o, dir);
+        const bool pass = active && rl_bound_pass(b, o, dir);
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
-            if (pass) queue[(q_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
-            q_tail += (uint32_t)__popcll(m);
-            if (q_tail - q_head >= 64u) {
-                process(64u);
-                q_head += 64u;
+            if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
+            a_tail += (uint32_t)__popcll(m);
+            if (a_tail - a_head >= 64u) {
+                process_prisms(64u);
+                a_head += 64u;
             }
         }
     }
-    if (q_tail != q_head) process(q_tail - q_head);
+    if (a_tail != a_head) process_prisms(a_tail - a_head);
+
     rl_wave_sync();
     const unsigned long long k = keys[lane];
     const uint32_t low = (uint32_t)k;
@@ -256,8 +303,10 @@ __global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __res
     sv.objects = base + lay.off_objects;
     sv.cie = base + lay.off_cie;
     sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
-    sv.n_spheres = lay.n_spheres;
-    sv.n_spheres_padded = lay.n_spheres_padded;
+    sv.n_direct = lay.n_direct;
+    sv.n_direct_padded = lay.n_direct_padded;
+    sv.cluster_base = lay.cluster_base;
+    sv.n_clusters = lay.n_clusters;
     sv.n_planes = lay.n_planes;
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;
@@ -266,7 +315,6 @@ __global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __res
     sv.screen_distance = lay.screen_distance;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t lane_below = (1ull << lane) - 1ull;
     RlWaveScratch* ws = &wave_scratch[threadIdx.x >> 6];
 
     uint64_t chunk_next = 0, chunk_end = 0; // wave-uniform
@@ -313,7 +361,7 @@ __global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __res
             if (chunk_next >= job.n_paths) drained = true;
         }
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane, lane_below);
+        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane);
         if (active) {
             segments += 1;
             float value;

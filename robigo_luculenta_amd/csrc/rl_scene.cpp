@@ -2,9 +2,11 @@
 // RlSceneDesc into the 16-byte records of rl_scene.h.  Pure host code (no device needed).
 #include "rl_scene.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <numeric>
 
 #include "rl_core.h"
 
@@ -214,6 +216,69 @@ RlF4 prism_bound(const RlF4* pr) {
     return r;
 }
 
+struct SphereIn {
+    RlF4 rec;      // {centre, radius^2}
+    uint32_t obj;
+    double radius;
+};
+
+// Splits sphere indices into spatially compact groups of at most RL_CLUSTER_K by recursive median
+// cuts along the longest axis of the centres.
+void split_clusters(const std::vector<SphereIn>& sph, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out) {
+    if (idx.size() <= RL_CLUSTER_K) {
+        if (!idx.empty()) out.push_back(idx);
+        return;
+    }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i : idx) {
+        const double c[3] = {sph[i].rec.x, sph[i].rec.y, sph[i].rec.z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+        }
+    }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+    auto coord = [&](uint32_t i) { return axis == 0 ? sph[i].rec.x : axis == 1 ? sph[i].rec.y : sph[i].rec.z; };
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return coord(a) < coord(b) || (coord(a) == coord(b) && a < b); });
+    size_t left = ((idx.size() / 2 + RL_CLUSTER_K - 1) / RL_CLUSTER_K) * RL_CLUSTER_K; // full leaves on the left
+    if (left >= idx.size()) left = idx.size() - RL_CLUSTER_K;
+    split_clusters(sph, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out);
+    split_clusters(sph, std::vector<uint32_t>(idx.begin() + left, idx.end()), out);
+}
+
+// Bounding sphere of a cluster: centre by a few "move towards the farthest member" steps, radius =
+// max(|centre - c_i| + r_i), inflated by 5 % + 0.05 so that neither float rounding in the cull test
+// nor the reference's treatment of slightly un-normalised directions (material.rs:246, which its
+// sphere test ignores, geometry.rs:207) can make the cull reject a sphere the reference would hit.
+RlF4 cluster_bound(const std::vector<SphereIn>& sph, const std::vector<uint32_t>& members) {
+    double c[3] = {0, 0, 0};
+    for (uint32_t i : members) {
+        c[0] += sph[i].rec.x; c[1] += sph[i].rec.y; c[2] += sph[i].rec.z;
+    }
+    for (int a = 0; a < 3; ++a) c[a] /= (double)members.size();
+    auto reach = [&](uint32_t i) {
+        const double dx = sph[i].rec.x - c[0], dy = sph[i].rec.y - c[1], dz = sph[i].rec.z - c[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz) + sph[i].radius;
+    };
+    for (int it = 0; it < 64; ++it) {
+        uint32_t far = members[0];
+        for (uint32_t i : members)
+            if (reach(i) > reach(far)) far = i;
+        const double step = 0.5 / (it + 2.0);
+        c[0] += (sph[far].rec.x - c[0]) * step; c[1] += (sph[far].rec.y - c[1]) * step; c[2] += (sph[far].rec.z - c[2]) * step;
+    }
+    double radius = 0;
+    for (uint32_t i : members) radius = std::max(radius, reach(i));
+    radius = radius * 1.05 + 0.05;
+    RlF4 b;
+    b.x = (float)c[0]; b.y = (float)c[1]; b.z = (float)c[2];
+    b.w = (float)(radius * radius);
+    if (!(radius < 1e15)) b.w = std::numeric_limits<float>::infinity();
+    return b;
+}
+
 } // namespace
 
 uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, RlCameraDesc* camera) {
@@ -234,6 +299,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     }
     RlFlatScene& fs = *out;
     fs = RlFlatScene();
+    std::vector<SphereIn> sph_in;
     fs.camera = desc->camera;
     const float fov = PI * desc->camera.fov_over_pi;
     fs.screen_distance = 1.0f / rl_tanf(fov * 0.5f); // camera.rs:56
@@ -242,11 +308,15 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         const float objbits = rl_u2f(i);
         uint32_t group_index = 0;
         switch (o.surface_kind) {
-        case RL_SURFACE_SPHERE:
-            group_index = (uint32_t)fs.spheres.size();
-            fs.spheres.push_back(F4(F(o.v0), o.f0 * o.f0)); // geometry.rs:195-200
-            fs.sphere_obj.push_back(i);
+        case RL_SURFACE_SPHERE: {
+            SphereIn si;
+            si.rec = F4(F(o.v0), o.f0 * o.f0); // geometry.rs:195-200
+            si.obj = i;
+            si.radius = std::fabs((double)o.f0);
+            sph_in.push_back(si);
+            group_index = 0; // patched below, once the record's final position is known
             break;
+        }
         case RL_SURFACE_PLANE:
         case RL_SURFACE_CIRCLE:
             group_index = (uint32_t)(fs.planes.size() / 2);
@@ -291,12 +361,51 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         fs.objects.push_back(a);
         fs.objects.push_back(b);
     }
-    // Dummy spheres that can never be hit: c = |co|^2 - (-inf) = +inf, q = -inf < 0.
-    fs.n_spheres = (uint32_t)fs.spheres.size();
-    fs.n_spheres_padded = (fs.n_spheres + 3u) & ~3u;
-    RlF4 dummy;
+    // ---- spheres: direct list + clusters ----
+    // Direct: spheres much larger than the typical one (a bound around them would cull nothing), and
+    // everything when the scene has too few spheres for clusters to pay.
+    std::vector<uint32_t> direct, clustered;
+    {
+        std::vector<double> radii;
+        for (const SphereIn& si : sph_in) radii.push_back(si.radius);
+        double median = 0;
+        if (!radii.empty()) {
+            std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+            median = radii[radii.size() / 2];
+        }
+        const bool use_clusters = sph_in.size() >= 4 * RL_CLUSTER_K;
+        for (uint32_t k = 0; k < sph_in.size(); ++k) {
+            if (!use_clusters || sph_in[k].radius > 2.5 * median || !std::isfinite(sph_in[k].radius)) direct.push_back(k);
+            else clustered.push_back(k);
+        }
+    }
+    RlF4 dummy; // can never be hit: c = |co|^2 - (-inf) = +inf, q = -inf < 0
     dummy.x = dummy.y = dummy.z = 0.0f;
     dummy.w = -std::numeric_limits<float>::infinity();
-    fs.spheres.resize(fs.n_spheres_padded + 4, dummy);
+    auto place = [&](uint32_t k) {
+        const uint32_t pos = (uint32_t)fs.spheres.size();
+        fs.spheres.push_back(sph_in[k].rec);
+        fs.sphere_obj.push_back(sph_in[k].obj);
+        fs.objects[2 * sph_in[k].obj].y = rl_u2f(pos); // group index = record position
+    };
+    for (uint32_t k : direct) place(k);
+    fs.n_direct = (uint32_t)direct.size();
+    fs.n_direct_padded = (fs.n_direct + 3u) & ~3u;
+    fs.spheres.resize(fs.n_direct_padded + 4, dummy);
+    fs.sphere_obj.resize(fs.spheres.size(), RL_HIT_NONE);
+    fs.cluster_base = (uint32_t)fs.spheres.size();
+    std::vector<std::vector<uint32_t>> clusters;
+    split_clusters(sph_in, clustered, clusters);
+    for (std::vector<uint32_t>& members : clusters) {
+        std::sort(members.begin(), members.end()); // ascending object order inside a cluster
+        fs.spheres.push_back(cluster_bound(sph_in, members));
+        fs.sphere_obj.push_back(RL_HIT_NONE);
+        for (uint32_t k : members) place(k);
+        for (size_t pad = members.size(); pad < RL_CLUSTER_K; ++pad) {
+            fs.spheres.push_back(dummy);
+            fs.sphere_obj.push_back(RL_HIT_NONE);
+        }
+    }
+    fs.n_clusters = (uint32_t)clusters.size();
     return RL_OK;
 }

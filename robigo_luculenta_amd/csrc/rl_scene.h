@@ -6,6 +6,8 @@
 // 16-byte fetch (LDS broadcast or scalar load):
 //
 //   spheres   1 x RlF4 each : {centre.xyz, radius^2}                         geometry.rs:186-200
+//             "direct" spheres first (tested by every ray), then clusters of RL_CLUSTER_K spatially
+//             close spheres, each preceded by a {bounding-sphere centre, radius^2} record
 //   planes    2 x RlF4 each : {normal.xyz, radius^2 or -1}, {offset.xyz, obj} geometry.rs:35-51,130-150
 //   parabs    3 x RlF4 each : {offset.xyz, obj}, {normal.xyz, 0}, {focal_point.xyz, 0}   :269-295
 //   prisms   17 x RlF4 each : 8 half-spaces x ({normal.xyz, 0}, {offset.xyz, obj})       :409-515
@@ -15,12 +17,17 @@
 //   objects   2 x RlF4 each : {surface_kind | material_kind << 8, group index, 0, 0} as bits,
 //                             {m0, m1, m2, 0}  (black body: m0 = kelvins, m1 = normalisation factor)
 //
-// The sphere array is padded with never-hit dummies (radius^2 = -inf) to a multiple of 4 plus one
-// extra group of 4, so the kernel can unroll by 4 and prefetch one group ahead without a bounds check.
+// The direct sphere list is padded with never-hit dummies (radius^2 = -inf) to a multiple of 4 plus
+// one extra group of 4, so the kernel can unroll by 4 and prefetch one group ahead without a bounds
+// check; short clusters are padded with the same dummies.
 //
-// Spheres are scanned first with the reference's strict `<`; the other groups are merged with the
-// lexicographic (distance, object index) rule, which is exactly scene.rs:51's "first object wins".
-// sphere_obj maps a sphere's slot back to its object index.
+// Sphere clusters are NOT in the reference (its scan is flat, scene.rs:46).  They are a conservative
+// cull: a ray that misses a cluster's (inflated) bounding sphere cannot hit any member, so skipping
+// the members leaves Scene::intersect's result unchanged -- the parity tests check exactly that.
+//
+// All candidates are merged with the lexicographic (distance, object index) rule, which is
+// scene.rs:51's strict `<` over objects in scan order ("first object wins").  sphere_obj maps a
+// record position in `spheres` back to its object index.
 #pragma once
 #include <vector>
 
@@ -32,6 +39,8 @@ struct alignas(16) RlF4 {
 };
 
 #define RL_PRISM_STRIDE 17 // records per hexagonal prism: 16 half-space records + 1 bound
+#define RL_CLUSTER_K 8                         // spheres per cluster
+#define RL_CLUSTER_STRIDE (RL_CLUSTER_K + 1)   // + the bound record in front (odd stride: LDS banks)
 
 // Everything the per-path code needs to read; pointers are device or host memory depending on
 // who built the view.
@@ -43,8 +52,11 @@ struct RlSceneView {
     const RlF4* objects;
     const uint32_t* sphere_obj;
     const RlF4* cie; // RL_CIE_SAMPLES rows {X, Y, Z, 0}
-    uint32_t n_spheres, n_planes, n_parabs, n_prisms, n_objects;
-    uint32_t n_spheres_padded; // multiple of 4; records [n_spheres, n_spheres_padded + 4) are dummies
+    uint32_t n_planes, n_parabs, n_prisms, n_objects;
+    uint32_t n_direct;         // direct spheres: records [0, n_direct)
+    uint32_t n_direct_padded;  // multiple of 4; records [n_direct, n_direct_padded + 4) are dummies
+    uint32_t cluster_base;     // first cluster record (= n_direct_padded + 4)
+    uint32_t n_clusters;       // each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
     RlCameraDesc camera;
     float screen_distance; // 1 / tan(field_of_view / 2), camera.rs:56 (constant per scene)
 };
@@ -53,8 +65,7 @@ struct RlSceneView {
 struct RlFlatScene {
     std::vector<RlF4> spheres, planes, parabs, prisms, objects;
     std::vector<uint32_t> sphere_obj;
-    uint32_t n_spheres;        // real spheres; `spheres` also holds the dummy padding
-    uint32_t n_spheres_padded; // see RlSceneView
+    uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView
     RlCameraDesc camera;
     float screen_distance;
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).

@@ -35,8 +35,10 @@ void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDe
     v.objects = m->flat.objects.data();
     v.sphere_obj = m->flat.sphere_obj.data();
     v.cie = (const RlF4*)RL_CIE1931_XYZ0;
-    v.n_spheres = m->flat.n_spheres;
-    v.n_spheres_padded = m->flat.n_spheres_padded;
+    v.n_direct = m->flat.n_direct;
+    v.n_direct_padded = m->flat.n_direct_padded;
+    v.cluster_base = m->flat.cluster_base;
+    v.n_clusters = m->flat.n_clusters;
     v.n_planes = (uint32_t)(m->flat.planes.size() / 2);
     v.n_parabs = (uint32_t)(m->flat.parabs.size() / 3);
     v.n_prisms = (uint32_t)(m->flat.prisms.size() / RL_PRISM_STRIDE);
