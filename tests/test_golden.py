@@ -1,0 +1,70 @@
+"""Committed golden fixtures (tools/gen_golden.py): regression pins for the oracle and the kernel's
+per-path header on the CPU; the GPU test at the end checks the device against the same files without
+needing anything but the fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import _mirror as M
+import _oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_photon_fixture_oracle_and_core():
+    g = np.load(os.path.join(G, "demo_photons.npz"))
+    objs, cam = O.demo_scene_desc()
+    so, sm = O.Scene(objs, cam), M.Scene(objs, cam)
+    for (seed, stream, first), want, segs in zip(g["cases"], g["photons"], g["segments"]):
+        got, s1 = so.render(1280, 720, int(seed), int(stream), int(first), len(want))
+        assert got.tobytes() == want.tobytes() and s1 == segs
+        got, s2 = sm.render(1280, 720, int(seed), int(stream), int(first), len(want))
+        assert got.tobytes() == want.tobytes() and s2 == segs
+    p = g["photons"][0]
+    assert ((p["wavelength"] >= 380) & (p["wavelength"] <= 780)).all()
+    assert (np.abs(p["x"]) <= 1).all() and (np.abs(p["y"]) <= 720 / 1280 + 1e-6).all()
+    assert 0.05 < (p["probability"] > 0).mean() < 0.2 and p["probability"].min() >= 0
+
+
+def test_image_fixture_oracle():
+    g = np.load(os.path.join(G, "demo_image_64x36.npz"))
+    W, H, N = int(g["width"]), int(g["height"]), int(g["n_paths"])
+    objs, cam = O.demo_scene_desc()
+    ph, _ = O.Scene(objs, cam).render(W, H, 1, 0, 0, N, threads=8)
+    acc = np.zeros((W * H, 3), np.float32)
+    comp = np.zeros_like(acc)
+    O.accumulate(acc, comp, O.plot(W, H, ph[: N // 2]))
+    O.accumulate(acc, comp, O.plot(W, H, ph[N // 2:]))
+    assert acc.tobytes() == g["xyz"].tobytes() and comp.tobytes() == g["compensation"].tobytes()
+    rgb, srgb, mx = O.tonemap(acc, W, H)
+    assert rgb.tobytes() == g["rgb"].tobytes() and srgb.tobytes() == g["srgb"].tobytes()
+    assert np.float32(mx) == g["max_intensity"]
+    # image statistics: the sun is in the centre and saturates; the frame is not black
+    img = g["rgb"].reshape(H, W, 3)
+    assert img[H // 2 - 3, W // 2].min() > 200 and 20 < img.mean() < 160
+
+
+@pytest.mark.gpu
+def test_gpu_against_fixtures_only():
+    R = pytest.importorskip("robigo_luculenta_amd")
+    g = np.load(os.path.join(G, "demo_photons.npz"))
+    scene = R.Scene.builtin(R.SCENE_DEMO)
+    t = R.TraceUnit(0, 1280, 720, n_photons=g["photons"].shape[1])
+    for (seed, stream, first), want, segs in zip(g["cases"], g["photons"], g["segments"]):
+        before = t.stats()[1]
+        t.render(scene, seed=int(seed), stream=int(stream), first_path_index=int(first))
+        assert t.mapped_photons.tobytes() == want.tobytes()
+        assert t.stats()[1] - before == segs
+    gi = np.load(os.path.join(G, "demo_image_64x36.npz"))
+    W, H, N = int(gi["width"]), int(gi["height"]), int(gi["n_paths"])
+    tr, p, ga, tm = R.TraceUnit(1, W, H, n_photons=N // 2), R.PlotUnit(0, W, H), R.GatherUnit(W, H), R.TonemapUnit(W, H)
+    for k in range(2):
+        tr.render(scene, seed=1, stream=0, first_path_index=k * (N // 2))
+        p.plot([tr])
+        ga.accumulate(p)
+    tm.tonemap(ga)
+    srgb, mx = tm.srgb_float()
+    # float atomics re-order the per-pixel sums: north_star's tolerance is 1e-3 per sRGB channel
+    assert np.abs(srgb - gi["srgb"]).max() <= 1e-3
+    assert np.allclose(ga.tristimulus_buffer, gi["xyz"], rtol=2e-5, atol=1e-6 * np.abs(gi["xyz"]).max())

@@ -1,0 +1,82 @@
+"""The kernel's per-path header (csrc/rl_core.h: flat records, sphere clusters, prism culls) compiled
+with g++ must be bit-identical to the literal oracle -- this is the no-GPU half of the parity proof;
+tests/test_gpu_parity.py repeats it with the hipcc build on the device."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _mirror as M
+import _oracle as O
+
+
+def test_builtin_scene_desc_matches_oracle_restatement():
+    """The product's App::set_up_scene (rl_scene.cpp) against the oracle's own (rl_oracle.cpp)."""
+    for seeds in (0, 158, 7):
+        oo, oc = O.demo_scene_desc(seeds)
+        mo, mc = M.builtin_desc(0, seeds)
+        assert oo.tobytes() == mo.tobytes()
+        assert bytes(oc) == bytes(mc)
+
+
+def test_glass_stress_scene_inventory():
+    objs, cam = M.builtin_desc(1)
+    assert len(objs) == 7 + 66
+    assert list(np.bincount(objs["surface_kind"], minlength=5)) == [1, 1, 2, 3, 66]
+    assert (objs[7:]["material_kind"] == 4).all()
+    # three rings of 11 x 2 prisms (radius 10 / 17 / 24; the second variant of each pair stands at
+    # 1.2 x the radius, app.rs:291-296): six distinct distances from the axis, 11 prisms each
+    r = np.hypot(objs[7:]["v1"][:, 0].astype(np.float64), objs[7:]["v1"][:, 1])
+    groups = np.unique(np.round(r, 2), return_counts=True)
+    assert len(groups[0]) == 6 and (groups[1] == 11).all()
+
+
+@pytest.mark.parametrize("which,param,n", [(0, 0, 120000), (1, 0, 60000), (0, 158, 60000), (0, 3, 60000)])
+def test_core_bit_exact_vs_oracle(which, param, n):
+    objs, cam = M.builtin_desc(which, param)
+    so, sm = O.Scene(objs, cam), M.Scene(objs, cam)
+    want, segs = so.render(1280, 720, 11, 2, 10_000_000_000, n, threads=8)
+    got, segs2 = sm.render(1280, 720, 11, 2, 10_000_000_000, n)
+    assert segs == segs2
+    assert got.tobytes() == want.tobytes()
+
+
+def test_core_bit_exact_on_custom_scene_without_clusters():
+    """Fewer than 4*K spheres -> everything on the direct list; mixed primitives; ties between objects."""
+    objs, cam = M.builtin_desc(0)
+    pick = np.r_[0:7, 7:27, 207:215, 317:321]
+    sub = objs[pick].copy()
+    so, sm = O.Scene(sub, cam), M.Scene(sub, cam)
+    want, _ = so.render(640, 360, 5, 0, 0, 80000, threads=8)
+    got, _ = sm.render(640, 360, 5, 0, 0, 80000)
+    assert got.tobytes() == want.tobytes()
+    # duplicate objects: exact distance ties must resolve to the FIRST object (scene.rs:51)
+    dup = np.concatenate([sub, sub[7:27]])
+    dup[len(sub):]["material_kind"] = 3  # the duplicates are mirrors: a wrong tie-break changes the path
+    so, sm = O.Scene(dup, cam), M.Scene(dup, cam)
+    want, _ = so.render(640, 360, 5, 0, 0, 40000, threads=8)
+    got, _ = sm.render(640, 360, 5, 0, 0, 40000)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_duplicate_spheres_in_clusters_tie_to_first_object():
+    objs, cam = M.builtin_desc(0)
+    dup = np.concatenate([objs, objs[7:107]])
+    dup[len(objs):]["material_kind"] = 3
+    so, sm = O.Scene(dup, cam), M.Scene(dup, cam)
+    want, _ = so.render(640, 360, 6, 0, 0, 40000, threads=8)
+    got, _ = sm.render(640, 360, 6, 0, 0, 40000)
+    assert got.tobytes() == want.tobytes()
+
+
+def test_plot_weights_and_cie_lookup_bit_exact():
+    objs, cam = M.builtin_desc(0)
+    ph, _ = O.Scene(objs, cam).render(96, 54, 3, 0, 0, 200000, threads=8)
+    assert M.plot(96, 54, ph).tobytes() == O.plot(96, 54, ph).tobytes()
+    # edge photons: corners, out-of-gamut wavelengths
+    edge = np.zeros(6, dtype=O.PHOTON_DTYPE)
+    edge["x"] = [-1, 1, -1, 1, 0.999999, 0]
+    edge["y"] = [-0.5625, 0.5625, 0.5625, -0.5625, 0.1, 0]
+    edge["probability"] = 1.0
+    edge["wavelength"] = [380, 780, 379.0, 781.0, 555, 374.9]
+    assert M.plot(96, 54, edge).tobytes() == O.plot(96, 54, edge).tobytes()
