@@ -115,18 +115,16 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.first_path = first_path;
     job.n_paths = n_paths;
 
-    const size_t lds_bytes = scene->staged_bytes;
-    bool stage = (u->fetch == RL_FETCH_LDS) && lds_bytes <= 160 * 1024;
+    // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
+    const size_t blob_bytes = scene->staged_bytes;
+    const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     auto kernel = stage ? rl_trace_kernel<true> : rl_trace_kernel<false>;
-    const size_t dyn = stage ? lds_bytes : 0;
-    if (stage && lds_bytes > 64 * 1024)
-        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    int per_cu = 0;
-    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_BLOCK, dyn));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)per_cu;
-    const uint64_t needed = (n_paths + RL_BLOCK - 1) / RL_BLOCK;
+    const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
+    if (dyn > 64 * 1024)
+        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    uint64_t blocks = (uint64_t)u->cu_count;
+    const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
 
     EventPair ep;
@@ -139,7 +137,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     }
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
     RL_HIP(hipEventRecord(ep.start, u->stream));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
                        plot, u->queue);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));

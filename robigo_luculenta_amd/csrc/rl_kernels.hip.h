@@ -19,8 +19,9 @@
 #include "rl_cie1931.h"
 #include "rl_core.h"
 
-#define RL_BLOCK 256
-#define RL_CHUNK 256ull // paths a wave takes from the global queue at a time
+#define RL_BLOCK 256        // streaming kernels (plot, gather, tonemap)
+#define RL_TRACE_BLOCK 1024 // trace kernel: one workgroup of 16 waves per CU shares one LDS copy of the scene
+#define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills)
 
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
@@ -59,6 +60,10 @@ struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
+    // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy, then the
+    // path's offset in the launch (lo, hi; ~0 = no path).  Refilled with all 64 lanes busy.
+    float stash[9][64];
+    uint32_t stash_off[2][64];
 };
 
 // Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
@@ -282,18 +287,20 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
 
 // queue[0] = next unassigned path offset of this launch (zeroed before each launch),
 // queue[1] = cumulative segments, queue[2] = cumulative paths.
+// Dynamic LDS: [scene blob when STAGE_LDS][RlWaveScratch x 16].
 template <bool STAGE_LDS>
-__global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
-                                                            RlTraceJob job, RlMappedPhoton* __restrict__ photons,
-                                                            float* __restrict__ plot,
-                                                            unsigned long long* __restrict__ queue) {
+__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
+                                                                  RlTraceJob job, RlMappedPhoton* __restrict__ photons,
+                                                                  float* __restrict__ plot,
+                                                                  unsigned long long* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
-    __shared__ RlWaveScratch wave_scratch[RL_BLOCK / 64];
     const RlF4* base = scene;
+    RlWaveScratch* scratch = (RlWaveScratch*)smem;
     if (STAGE_LDS) {
-        for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_BLOCK) smem[i] = scene[i];
+        for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_TRACE_BLOCK) smem[i] = scene[i];
         __syncthreads();
         base = smem;
+        scratch = (RlWaveScratch*)(smem + lay.total_f4);
     }
     RlSceneView sv;
     sv.spheres = base;
@@ -315,10 +322,14 @@ __global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __res
     sv.screen_distance = lay.screen_distance;
 
     const uint32_t lane = threadIdx.x & 63u;
-    RlWaveScratch* ws = &wave_scratch[threadIdx.x >> 6];
+    RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
+    typedef __attribute__((address_space(3))) float RlLdsF32;
+    RlLdsF32* stash = (RlLdsF32*)&ws->stash[0][0];
+    RlLdsU32* stash_off = (RlLdsU32*)&ws->stash_off[0][0];
 
-    uint64_t chunk_next = 0, chunk_end = 0; // wave-uniform
-    bool drained = false;                   // wave-uniform
+    uint64_t chunk_next = 0, chunk_end = 0;     // wave-uniform: this wave's slice of the global queue
+    uint32_t stash_head = 0, stash_count = 0;   // wave-uniform
+    bool drained = false;                       // wave-uniform: the queue has no more paths for this wave
     bool active = false;
     uint64_t my_offset = 0;
     RlPath p;
@@ -332,33 +343,64 @@ __global__ __launch_bounds__(RL_BLOCK, 4) void rl_trace_kernel(const RlF4* __res
     uint32_t segments = 0, paths_done = 0;
 
     for (;;) {
-        const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
-        if (need != 0 && !drained) {
-            const uint32_t cnt = (uint32_t)__popcll(need);
-            const uint32_t rank = rl_mbcnt(need);
-            const uint64_t avail = chunk_end - chunk_next;
-            const uint64_t base0 = chunk_next;
-            uint64_t base1 = 0;
-            if (avail < cnt) {
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(&queue[0], RL_CHUNK);
-                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
-                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-                base1 = ((uint64_t)hi << 32) | lo;
-                chunk_next = base1 + (cnt - avail);
-                chunk_end = base1 + RL_CHUNK;
-            } else {
-                chunk_next += cnt;
+        // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
+        for (;;) {
+            const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
+            if (need == 0) break;
+            const uint32_t avail = stash_count - stash_head;
+            if (avail == 0) {
+                if (drained) break;
+                // Refill: all 64 lanes generate one camera ray each (full exec mask) into the stash.
+                if (chunk_next == chunk_end) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(&queue[0], RL_CHUNK);
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+                    chunk_next = ((uint64_t)hi << 32) | lo;
+                    chunk_end = chunk_next + RL_CHUNK;
+                }
+                const uint64_t offset = chunk_next + lane;
+                chunk_next += 64;
+                const bool valid = offset < job.n_paths;
+                RlPath fresh = p;
+                if (valid) rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, job.first_path + offset, &fresh);
+                rl_wave_sync();
+                stash[0 * 64 + lane] = fresh.origin.x;
+                stash[1 * 64 + lane] = fresh.origin.y;
+                stash[2 * 64 + lane] = fresh.origin.z;
+                stash[3 * 64 + lane] = fresh.direction.x;
+                stash[4 * 64 + lane] = fresh.direction.y;
+                stash[5 * 64 + lane] = fresh.direction.z;
+                stash[6 * 64 + lane] = fresh.wavelength;
+                stash[7 * 64 + lane] = fresh.sx;
+                stash[8 * 64 + lane] = fresh.sy;
+                stash_off[lane] = valid ? (uint32_t)offset : 0xffffffffu;
+                stash_off[64 + lane] = valid ? (uint32_t)(offset >> 32) : 0xffffffffu;
+                rl_wave_sync();
+                stash_head = 0;
+                stash_count = 64;
+                if (chunk_next >= job.n_paths) drained = true;
+                continue;
             }
-            if (!active) {
-                const uint64_t offset = (rank < avail) ? base0 + rank : base1 + (rank - avail);
-                if (offset < job.n_paths) {
-                    my_offset = offset;
-                    rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, job.first_path + offset, &p);
+            const uint32_t rank = rl_mbcnt(need);
+            if (!active && rank < avail) {
+                const uint32_t slot = stash_head + rank;
+                const uint32_t lo = stash_off[slot], hi = stash_off[64 + slot];
+                if ((lo & hi) != 0xffffffffu) {
+                    my_offset = ((uint64_t)hi << 32) | lo;
+                    p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
+                    p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
+                    p.wavelength = stash[6 * 64 + slot];
+                    p.sx = stash[7 * 64 + slot];
+                    p.sy = stash[8 * 64 + slot];
+                    p.intensity = 1.0f;
+                    p.continue_chance = 1.0f;
+                    p.bounce = 0;
                     active = true;
                 }
             }
-            if (chunk_next >= job.n_paths) drained = true;
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            stash_head += wanted < avail ? wanted : avail;
         }
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane);
