@@ -232,6 +232,42 @@ int rl_scheduler_get_new_task(RlScheduler* s, const RlTask* completed, int64_t n
  * (task_scheduler.rs:308-325). */
 int rl_scheduler_performance(RlScheduler* s, float* mean, float* stddev);
 
+/* ---- App (app.rs:48-164) ----------------------------------------------------------------------- */
+
+typedef struct RlAppConfig {
+    uint32_t width, height;      /* main.rs:47-48 (1280 x 720 there) */
+    int device;                  /* GPU that takes the place of the CPU worker pool */
+    uint32_t concurrency;        /* worker threads; the reference uses num_cpus::get() (app.rs:55) */
+    uint32_t photons_per_batch;  /* 0 -> 1024*512 (trace_unit.rs:67) */
+    uint64_t seed;
+    uint32_t stream;             /* RNG stream (multi-GPU: the rank) */
+    int builtin_scene;           /* enum RlBuiltinScene */
+    int builtin_param;
+    uint64_t max_batches;        /* stop after this many trace tasks (the reference never stops, main.rs:57) */
+    int64_t tonemap_interval_ms; /* 30000 in the reference (task_scheduler.rs:44-46) */
+    int fused;                   /* 0: Trace fills mapped_photons, Plot splats them (reference structure);
+                                    1: Trace renders straight into the plot unit it will be plotted by */
+    const char* output_ppm;      /* written after every tonemap (binary P6); NULL = none.  Replaces output.png (main.rs:61) */
+    const char* checkpoint;      /* GatherUnit::save target, written at every tonemap and at the end; NULL = none */
+    int resume;                  /* non-zero: rl_gather_unit_load(checkpoint) before rendering (gather_unit.rs:42-43) */
+    int verbose;                 /* print the reference's progress lines (task_scheduler.rs:242-325) */
+} RlAppConfig;
+
+typedef struct RlAppStats {
+    uint64_t batches, paths, segments;
+    uint64_t tasks[5];           /* executed tasks by RlTaskKind */
+    double seconds;
+    double kernel_ms;            /* device time in trace kernels */
+    float batches_per_sec_mean, batches_per_sec_stddev; /* task_scheduler.rs:308-325 */
+    uint32_t tonemaps;
+} RlAppStats;
+
+/* App::new + the worker loops (app.rs:54-111) until max_batches trace tasks are done, gathered and
+ * tonemapped once more.  Trace task number k (in scheduler order) renders paths
+ * [k * photons_per_batch, (k + 1) * photons_per_batch), so the final image does not depend on which
+ * worker or unit ran which task.  rgb_out (may be NULL) receives the last RGB8 image. */
+int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
+
 /* ---- diagnostics -------------------------------------------------------------------------------- */
 
 /* Not a reference interface: evaluates the shared numerics header (csrc/rl_math.h) on the GPU so a

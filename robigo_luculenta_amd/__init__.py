@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (RlCameraDesc, RlError, RlMappedPhoton, RlObjectDesc, RlSceneDesc, RlTask, RlVector3, check, lib,
+from ._lib import (RlAppConfig, RlAppStats, RlCameraDesc, RlError, RlMappedPhoton, RlObjectDesc, RlSceneDesc, RlTask, RlVector3, check, lib,
                    RL_TASK_MAX_UNITS)
 
 PHOTON_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("probability", "<f4"), ("wavelength", "<f4")])
@@ -251,6 +251,22 @@ class TaskScheduler(_Handle):
         m, s = C.c_float(0), C.c_float(0)
         check(lib.rl_scheduler_performance(self._h, C.byref(m), C.byref(s)))
         return m.value, s.value
+
+
+def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_batch=NUMBER_OF_PHOTONS, seed=1, stream=0,
+            scene=SCENE_DEMO, scene_param=0, tonemap_interval_ms=30000, fused=False, output_ppm=None, checkpoint=None,
+            resume=False, verbose=False):
+    """App::new + worker loops (app.rs:54-111) on one GPU until `max_batches` trace tasks are done.
+    Returns (rgb image as (H, W, 3) uint8, stats dict)."""
+    cfg = RlAppConfig(width, height, device, concurrency, photons_per_batch, seed, stream, scene, scene_param, max_batches,
+                      tonemap_interval_ms, int(fused), output_ppm.encode() if output_ppm else None,
+                      checkpoint.encode() if checkpoint else None, int(resume), int(verbose))
+    stats = RlAppStats()
+    rgb = np.zeros((height, width, 3), dtype=np.uint8)
+    check(lib.rl_app_run(C.byref(cfg), C.byref(stats), rgb.ctypes.data_as(C.c_void_p)))
+    out = {name: getattr(stats, name) for name, _ in RlAppStats._fields_ if name != "tasks"}
+    out["tasks"] = dict(zip(["sleep", "trace", "plot", "gather", "tonemap"], list(stats.tasks)))
+    return rgb, out
 
 
 def math_probe(fn, x, device=0):

@@ -45,6 +45,20 @@ class RlTask(C.Structure):
                 ("units", C.c_uint32 * RL_TASK_MAX_UNITS)]
 
 
+class RlAppConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("device", C.c_int), ("concurrency", C.c_uint32),
+                ("photons_per_batch", C.c_uint32), ("seed", C.c_uint64), ("stream", C.c_uint32),
+                ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
+                ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
+                ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int)]
+
+
+class RlAppStats(C.Structure):
+    _fields_ = [("batches", C.c_uint64), ("paths", C.c_uint64), ("segments", C.c_uint64), ("tasks", C.c_uint64 * 5),
+                ("seconds", C.c_double), ("kernel_ms", C.c_double), ("batches_per_sec_mean", C.c_float),
+                ("batches_per_sec_stddev", C.c_float), ("tonemaps", C.c_uint32)]
+
+
 # name -> (restype, argtypes); every symbol include/robigo_luculenta.h declares.
 _vp, _u8p = C.c_void_p, C.c_void_p
 _i, _u32, _u64, _i64, _f = C.c_int, C.c_uint32, C.c_uint64, C.c_int64, C.c_float
@@ -85,6 +99,7 @@ SIGNATURES = {
     "rl_scheduler_destroy": (_i, [_vp]),
     "rl_scheduler_get_new_task": (_i, [_vp, C.POINTER(RlTask), _i64, C.POINTER(RlTask)]),
     "rl_scheduler_performance": (_i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
+    "rl_app_run": (_i, [C.POINTER(RlAppConfig), C.POINTER(RlAppStats), _vp]),
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
 }
 

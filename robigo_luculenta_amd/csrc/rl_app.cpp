@@ -1,0 +1,279 @@
+// rl_app.cpp -- App (app.rs:48-164): the worker pool that asks the TaskScheduler for tasks and
+// executes them, with the GPU units of the C ABI where the reference has CPU loops.
+//
+// Same structure as the reference: `concurrency` OS threads, one Mutex around the scheduler
+// (app.rs:57,107), tasks executed outside the lock, Sleep = 100 ms (app.rs:129).  Differences, all
+// forced by "the reference never terminates and is unseedable": a batch budget (max_batches), a path
+// range per trace task, and explicit checkpoint / image file names.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/robigo_luculenta.h"
+
+namespace {
+
+struct AppState {
+    const RlAppConfig* cfg;
+    RlScheduler* scheduler = nullptr;
+    RlScene* scene = nullptr;
+    std::vector<RlTraceUnit*> trace_units;
+    std::vector<RlPlotUnit*> plot_units;
+    RlGatherUnit* gather = nullptr;
+    RlTonemapUnit* tonemap = nullptr;
+    std::mutex lock;                       // Arc<Mutex<TaskScheduler>>, app.rs:57
+    std::chrono::steady_clock::time_point t0;
+    uint64_t traces_issued = 0;            // under `lock`
+    std::vector<uint64_t> trace_first_path; // per trace unit: the path range of its current task
+    std::vector<int> trace_target_plot;    // fused mode: plot unit that received the unit's photons (-1 none)
+    uint64_t tasks[5] = {0, 0, 0, 0, 0};
+    uint32_t tonemaps = 0;
+    std::atomic<int> error{0};
+    std::string error_message;
+    std::vector<uint8_t> rgb;
+    uint32_t photons;
+};
+
+int64_t now_ms(const AppState& a) {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - a.t0).count();
+}
+
+void fail(AppState& a, int rc) {
+    int expected = 0;
+    if (a.error.compare_exchange_strong(expected, rc)) a.error_message = rl_last_error();
+}
+
+int write_ppm(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return RL_E_IO;
+    std::fprintf(f, "P6\n%u %u\n255\n", w, h);
+    const size_t n = (size_t)w * h * 3;
+    const size_t written = std::fwrite(rgb, 1, n, f);
+    return (std::fclose(f) == 0 && written == n) ? RL_OK : RL_E_IO;
+}
+
+// App::execute_task (app.rs:113-126)
+void execute_task(AppState& a, const RlTask& task) {
+    const RlAppConfig& c = *a.cfg;
+    int rc = RL_OK;
+    switch (task.kind) {
+    case RL_TASK_SLEEP: // app.rs:128-130
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        break;
+    case RL_TASK_TRACE: // app.rs:132-134
+        if (!c.fused) rc = rl_trace_unit_render(a.trace_units[task.unit], a.scene, c.seed, c.stream, a.trace_first_path[task.unit]);
+        // fused: the photons are produced when the unit is plotted (the target buffer is known then)
+        break;
+    case RL_TASK_PLOT: // app.rs:136-141
+        if (!c.fused) {
+            std::vector<RlTraceUnit*> units;
+            for (uint32_t i = 0; i < task.n_units; ++i) units.push_back(a.trace_units[task.units[i]]);
+            rc = rl_plot_unit_plot(a.plot_units[task.unit], units.data(), (uint32_t)units.size());
+        } else {
+            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) {
+                RlTraceUnit* t = a.trace_units[task.units[i]];
+                rc = rl_trace_unit_render_fused(t, a.scene, a.plot_units[task.unit], c.seed, c.stream,
+                                                a.trace_first_path[task.units[i]], a.photons);
+                if (rc == RL_OK) rc = rl_trace_unit_sync(t);
+            }
+        }
+        break;
+    case RL_TASK_GATHER: // app.rs:143-152 (save moved to tonemap time)
+        for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) rc = rl_gather_unit_accumulate(a.gather, a.plot_units[task.units[i]]);
+        break;
+    case RL_TASK_TONEMAP: // app.rs:154-164
+        rc = rl_tonemap_unit_tonemap(a.tonemap, a.gather);
+        if (rc == RL_OK) rc = rl_tonemap_unit_rgb(a.tonemap, a.rgb.data());
+        if (rc == RL_OK && c.output_ppm) rc = write_ppm(c.output_ppm, a.rgb.data(), c.width, c.height);
+        if (rc == RL_OK && c.checkpoint) rc = rl_gather_unit_save(a.gather, c.checkpoint);
+        if (rc == RL_OK && c.verbose && c.output_ppm) std::printf("wrote image to %s\n", c.output_ppm);
+        break;
+    default: break;
+    }
+    if (rc != RL_OK) fail(a, rc);
+}
+
+void log_completed(const AppState& a, const RlTask& t) { // task_scheduler.rs:241-296
+    switch (t.kind) {
+    case RL_TASK_TRACE: std::printf("done tracing with unit %u\n", t.unit); break;
+    case RL_TASK_PLOT:
+        std::printf("done plotting with unit %u\nthe following trace units are available again: ", t.unit);
+        for (uint32_t i = 0; i < t.n_units; ++i) std::printf(" %u ", t.units[i]);
+        std::printf("\n");
+        break;
+    case RL_TASK_GATHER:
+        std::printf("done gathering\nthe following plot units are available again: ");
+        for (uint32_t i = 0; i < t.n_units; ++i) std::printf(" %u ", t.units[i]);
+        std::printf("\n");
+        break;
+    case RL_TASK_TONEMAP: std::printf("done tonemapping\n"); break;
+    default: break;
+    }
+    (void)a;
+}
+
+// App::start_worker's loop (app.rs:92-111), ending when the batch budget is exhausted.
+void worker(AppState* ap) {
+    AppState& a = *ap;
+    RlTask task;
+    std::memset(&task, 0, sizeof task);
+    task.kind = RL_TASK_SLEEP; // "this worker is done sleeping" (app.rs:98-99)
+    for (;;) {
+        RlTask next;
+        {
+            std::lock_guard<std::mutex> guard(a.lock);
+            if (a.cfg->verbose) log_completed(a, task);
+            const bool budget_left = a.traces_issued < a.cfg->max_batches;
+            if (rl_scheduler_get_new_task(a.scheduler, &task, now_ms(a), &next) != RL_OK) {
+                fail(a, RL_E_INVALID);
+                return;
+            }
+            if (next.kind == RL_TASK_TRACE) {
+                if (!budget_left) {
+                    // Out of budget: hand the unit straight back as an un-rendered no-op is not possible in
+                    // the reference's protocol, so leave it out of circulation and stop this worker.
+                    return;
+                }
+                a.trace_first_path[next.unit] = a.traces_issued * (uint64_t)a.photons;
+                a.traces_issued += 1;
+            }
+            if (next.kind == RL_TASK_TONEMAP) a.tonemaps += 1;
+            a.tasks[next.kind] += 1;
+            if (a.cfg->verbose && next.kind == RL_TASK_TONEMAP) {
+                float mean = 0, sd = 0;
+                if (rl_scheduler_performance(a.scheduler, &mean, &sd) == RL_OK && mean == mean)
+                    std::printf("performance: %g +- %g batches/sec\n", mean, sd);
+            }
+        }
+        execute_task(a, next);
+        if (a.error.load() != 0) return;
+        task = next;
+    }
+}
+
+} // namespace
+
+extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out) {
+    if (!config || config->width == 0 || config->height == 0 || config->concurrency == 0) return RL_E_INVALID;
+    AppState a;
+    a.cfg = config;
+    a.photons = config->photons_per_batch ? config->photons_per_batch : 1024u * 512u;
+    a.rgb.assign((size_t)config->width * config->height * 3, 0);
+    const uint32_t n_trace = config->concurrency * 3;                          // task_scheduler.rs:95
+    const uint32_t n_plot = config->concurrency / 2 > 1 ? config->concurrency / 2 : 1; // :96
+    int rc = rl_scheduler_create(config->concurrency, config->tonemap_interval_ms, &a.scheduler);
+
+    std::vector<RlObjectDesc> objects;
+    RlCameraDesc camera;
+    uint32_t n_objects = 0;
+    if (rc == RL_OK) {
+        rl_scene_builtin_desc(config->builtin_scene, config->builtin_param, nullptr, 0, &n_objects, &camera);
+        objects.resize(n_objects);
+        rc = rl_scene_builtin_desc(config->builtin_scene, config->builtin_param, objects.data(), n_objects, &n_objects, &camera);
+    }
+    if (rc == RL_OK) {
+        RlSceneDesc desc;
+        desc.n_objects = n_objects;
+        desc.objects = objects.data();
+        desc.camera = camera;
+        rc = rl_scene_create(&desc, config->device, &a.scene); // Arc::new(App::set_up_scene()), app.rs:63
+    }
+    for (uint32_t i = 0; i < n_trace && rc == RL_OK; ++i) {
+        RlTraceUnit* u = nullptr;
+        rc = rl_trace_unit_create(config->device, i, config->width, config->height, a.photons, &u);
+        if (u) a.trace_units.push_back(u);
+    }
+    for (uint32_t i = 0; i < n_plot && rc == RL_OK; ++i) {
+        RlPlotUnit* u = nullptr;
+        rc = rl_plot_unit_create(config->device, i, config->width, config->height, nullptr, &u);
+        if (u) a.plot_units.push_back(u);
+    }
+    if (rc == RL_OK) rc = rl_gather_unit_create(config->device, config->width, config->height, &a.gather);
+    if (rc == RL_OK) rc = rl_tonemap_unit_create(config->device, config->width, config->height, &a.tonemap);
+    if (rc == RL_OK && config->resume && config->checkpoint) {
+        FILE* f = std::fopen(config->checkpoint, "rb"); // a missing file is not an error (gather_unit.rs:82)
+        if (f) {
+            std::fclose(f);
+            rc = rl_gather_unit_load(a.gather, config->checkpoint);
+        }
+    }
+    a.trace_first_path.assign(n_trace, 0);
+    a.trace_target_plot.assign(n_trace, -1);
+
+    if (rc == RL_OK) {
+        a.t0 = std::chrono::steady_clock::now();
+        std::vector<std::thread> pool;
+        for (uint32_t i = 0; i < config->concurrency; ++i) pool.emplace_back(worker, &a); // app.rs:66-70
+        for (std::thread& t : pool) t.join();
+        rc = a.error.load();
+    }
+    // Drain: every traced unit is plotted, every plot gathered, one final tonemap -- the same tasks the
+    // scheduler would have issued, run on this thread (workers stopped when the budget ran out).
+    if (rc == RL_OK) {
+        RlTask task;
+        std::memset(&task, 0, sizeof task);
+        task.kind = RL_TASK_SLEEP;
+        for (int guard = 0; guard < 100000; ++guard) {
+            RlTask next;
+            if (rl_scheduler_get_new_task(a.scheduler, &task, now_ms(a), &next) != RL_OK) {
+                rc = RL_E_INVALID;
+                break;
+            }
+            if (next.kind == RL_TASK_SLEEP) break; // nothing left to plot or gather
+            if (next.kind == RL_TASK_TRACE) {
+                // The scheduler prefers new traces over plotting (task_scheduler.rs:160-169); park the
+                // idle unit (never handed back) and ask again until only plot / gather work is left.
+                task.kind = RL_TASK_SLEEP;
+                task.n_units = 0;
+                continue;
+            }
+            a.tasks[next.kind] += 1;
+            if (next.kind == RL_TASK_TONEMAP) a.tonemaps += 1;
+            execute_task(a, next);
+            if ((rc = a.error.load()) != RL_OK) break;
+            task = next;
+        }
+    }
+    if (rc == RL_OK) {
+        RlTask final_task;
+        std::memset(&final_task, 0, sizeof final_task);
+        final_task.kind = RL_TASK_TONEMAP;
+        a.tasks[RL_TASK_TONEMAP] += 1;
+        a.tonemaps += 1;
+        execute_task(a, final_task);
+        rc = a.error.load();
+    }
+    const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - a.t0).count();
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->batches = a.traces_issued;
+        stats->seconds = seconds;
+        stats->tonemaps = a.tonemaps;
+        for (int k = 0; k < 5; ++k) stats->tasks[k] = a.tasks[k];
+        for (RlTraceUnit* u : a.trace_units) {
+            uint64_t p = 0, s = 0;
+            double ms = 0;
+            if (rl_trace_unit_stats(u, &p, &s, &ms) == RL_OK) {
+                stats->paths += p;
+                stats->segments += s;
+                stats->kernel_ms += ms;
+            }
+        }
+        if (a.scheduler) rl_scheduler_performance(a.scheduler, &stats->batches_per_sec_mean, &stats->batches_per_sec_stddev);
+    }
+    if (rgb_out && rc == RL_OK) std::memcpy(rgb_out, a.rgb.data(), a.rgb.size());
+    std::string message = a.error_message;
+    for (RlTraceUnit* u : a.trace_units) rl_trace_unit_destroy(u);
+    for (RlPlotUnit* u : a.plot_units) rl_plot_unit_destroy(u);
+    rl_gather_unit_destroy(a.gather);
+    rl_tonemap_unit_destroy(a.tonemap);
+    rl_scene_destroy(a.scene);
+    rl_scheduler_destroy(a.scheduler);
+    (void)message;
+    return rc;
+}

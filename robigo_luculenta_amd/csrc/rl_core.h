@@ -197,8 +197,13 @@ struct RlCand {
 // Compound::intersect's selection (geometry.rs:386-399) given both children's (already filtered)
 // candidates: nearest wins, tie -> second child.
 RL_HD RlCand rl_compound_pick(RlCand a, RlCand b) {
-    if (a.t >= 0.0f && b.t >= 0.0f) return (a.t < b.t) ? a : b;
-    return (a.t >= 0.0f) ? a : b;
+    // Field-wise selects (selecting whole structs makes the compiler spill both to scratch).
+    const bool a_some = a.t >= 0.0f, b_some = b.t >= 0.0f;
+    const bool take_a = (a_some && b_some) ? (a.t < b.t) : a_some;
+    RlCand r;
+    r.t = take_a ? a.t : b.t;
+    r.k = take_a ? a.k : b.k;
+    return r;
 }
 
 // HexagonalPrism = Compound<InfinitePrism[0,1,2], Compound<InfinitePrism[3,4,5], ThickPlane[6,7]>>

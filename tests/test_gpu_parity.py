@@ -3,6 +3,7 @@ outputs (per-photon records, Kahan buffers, exposure, tonemapped bytes) are comp
 only the atomically accumulated XYZ splat, whose summation order is not deterministic, gets a
 float tolerance (stated at each assert)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -202,3 +203,27 @@ def test_end_to_end_image_within_1e3(demo):
     _, want, _ = O.tonemap(acc, W, H)
     assert np.abs(got - want).max() <= 1e-3
     assert np.abs(tm.rgb_buffer.astype(int) - (want * 255).astype(np.uint8).astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("fused,concurrency", [(False, 1), (False, 3), (True, 2)])
+def test_app_worker_pool_renders_the_same_image_as_the_oracle(demo, fused, concurrency, tmp_path):
+    """App (csrc/rl_app.cpp = app.rs:48-164): scheduler + worker threads + units end to end."""
+    objs, cam, scene, oscene = demo
+    W, H, n, batches = 96, 54, 1 << 14, 14
+    ppm, raw = str(tmp_path / "output.ppm"), str(tmp_path / "buffer.raw")
+    rgb, st = R.app_run(W, H, batches, concurrency=concurrency, photons_per_batch=n, seed=3, fused=fused, output_ppm=ppm,
+                        checkpoint=raw)
+    assert st["batches"] == batches and st["paths"] == batches * n and st["tonemaps"] >= 1
+    assert st["tasks"]["trace"] == batches and st["tasks"]["plot"] >= 1 and st["tasks"]["gather"] >= 1
+    photons, segs = oscene.render(W, H, 3, 0, 0, batches * n, threads=8)
+    assert st["segments"] == segs
+    xyz = O.plot(W, H, photons)
+    want_rgb, want_srgb, _ = O.tonemap(xyz, W, H)
+    # batches are plotted/gathered in a thread-dependent order: float sums differ in the last bits only
+    assert np.abs(rgb.reshape(-1, 3).astype(int) - want_rgb.astype(int)).max() <= 1
+    data = open(ppm, "rb").read()
+    assert data.startswith(b"P6\n%d %d\n255\n" % (W, H)) and data[-W * H * 3:] == rgb.tobytes()
+    assert os.path.getsize(raw) == 2 * W * H * 12      # gather_unit.rs:68-78
+    # resume from the checkpoint: rendering 0 more batches reproduces the image from buffer.raw alone
+    rgb2, st2 = R.app_run(W, H, 0, concurrency=1, photons_per_batch=n, seed=3, checkpoint=raw, resume=True)
+    assert st2["batches"] == 0 and rgb2.tobytes() == rgb.tobytes()
