@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--fetch", default="lds", choices=["lds", "global"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo stages the XYZ reduce through host memory and lets several "
+                         "ranks share one GPU -- only for exercising the N > 1 code path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,11 +114,15 @@ def main():
 
     if R.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    device = local_rank
+    device = local_rank % R.device_count() if args.dist_backend == "gloo" else local_rank
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    on_device = args.dist_backend == "nccl"
 
     scene_name, param, W, H = CONFIGS[args.config]
     which = R.SCENE_DEMO if scene_name.startswith("demo") else R.SCENE_GLASS_STRESS
@@ -137,8 +144,13 @@ def main():
         next_path[0] += paths_per_step
         if (i + 1) % args.gather_every == 0:
             trace.sync()
-            if world > 1:
+            if world > 1 and on_device:
                 dist.reduce(xyz, dst=0, op=dist.ReduceOp.SUM)  # GatherUnit-time exchange over xGMI
+            elif world > 1:
+                host = xyz.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    xyz.copy_(host)
             if rank == 0:
                 gather.accumulate(plot)   # Kahan + clear (gather_unit.rs:49-64, app.rs:147)
             else:
@@ -165,7 +177,8 @@ def main():
     rays, paths, kernel_ms = s1 - s0, p1 - p0, ms1 - ms0
 
     if world > 1:
-        t = torch.tensor([elapsed, float(rays), float(paths), kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(rays), float(paths), kernel_ms], dtype=torch.float64,
+                         device="cuda" if on_device else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
