@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one fused TraceUnit::render + PlotUnit::plot launch over `--batches-per-step` batches
+One "step" = one fused TraceUnit::render + PlotUnit::plot launch over `--batches-per-step` (default 256) batches
 of 524,288 camera paths (trace_unit.rs:67) of the built-in demo scene (app.rs:166-363), followed,
 every `--gather-every` steps, by the GatherUnit step (Kahan accumulate + clear; with N > 1 the XYZ
 plot buffers are first sum-reduced to rank 0 over RCCL).  Every rank renders the full frame with its
@@ -87,11 +87,11 @@ def cpu_baseline(objs, cam, width, height, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="demo-1080p", choices=sorted(CONFIGS))
-    ap.add_argument("--batches-per-step", type=int, default=64)
-    ap.add_argument("--gather-every", type=int, default=4)
+    ap.add_argument("--batches-per-step", type=int, default=256)
+    ap.add_argument("--gather-every", type=int, default=2)
     ap.add_argument("--fetch", default="lds", choices=["lds", "global"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
