@@ -346,15 +346,17 @@ struct RlIsect {
     RlF3 position, normal, tangent;
 };
 
+// `want_tangent`: only the soap bubble reads Intersection.tangent (material.rs:294); the reference
+// computes it for every sphere hit (geometry.rs:250-251), which is unobservable for other materials.
 RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit& hit, uint32_t surface_kind,
-                            uint32_t group_index) {
+                            uint32_t group_index, bool want_tangent) {
     RlIsect is;
     is.position = rl_add(o, rl_mul(dir, hit.t));
     is.tangent = rl_f3(0.0f, 0.0f, 0.0f);
     if (surface_kind == RL_SURFACE_SPHERE) {
         const RlF4 s = sv.spheres[group_index];
         is.normal = rl_normalise(rl_sub(is.position, rl_xyz(s)));
-        is.tangent = rl_normalise(rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal));
+        if (want_tangent) is.tangent = rl_normalise(rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal));
     } else if (surface_kind == RL_SURFACE_PARABOLOID) {
         const RlF3 offset = rl_xyz(sv.parabs[3 * group_index]);
         const RlF3 normal = rl_xyz(sv.parabs[3 * group_index + 1]);
@@ -413,7 +415,8 @@ RL_HD bool rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint
         *value = p->intensity * ((float)rl_boltzmann((double)p->wavelength, (double)ob.x) * ob.y);
         return true;
     }
-    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y));
+    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y),
+                                     material_kind == RL_MATERIAL_SOAP_BUBBLE);
     const RlRngBlock rb = rl_rng_block(seed, stream, path_index, 2u + p->bounce);
     const RlF3 in_dir = p->direction;
     RlF3 new_dir;
