@@ -26,6 +26,10 @@ BATCH = 1024 * 512  # trace_unit.rs:67
 # (SURVEY 8d): sphere 19, paraboloid 38, plane / circle / half-space 14.
 FLOPS_SPHERE, FLOPS_PARABOLOID, FLOPS_PLANE = 19, 38, 14
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
+# HBM-side bytes per traced path of rl_trace_kernel from the committed PMC passes of this same command
+# (profiles/r01b_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE) KB per 134,217,728-path launch); the
+# counters cannot be read from inside this process, so `roofline.traffic` scales that measurement.
+PROFILED_TRAFFIC_BYTES_PER_PATH = (2 * 402.2 + 5.309e6) * 1024 / 134217728
 
 CONFIGS = {
     # name: (scene, param, width, height)
@@ -209,7 +213,10 @@ def main():
             "batches_per_s": total_paths / elapsed / BATCH,
             "segments_per_path": total_rays / max(total_paths, 1.0),
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "traffic": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step,
+                         "traffic_note": "bytes per launch, scaled from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/ "
+                                         "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms,
                          "algorithmic_flops_per_ray": f_seg,
                          "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only"},

@@ -247,7 +247,8 @@ typedef struct RlAppConfig {
     int64_t tonemap_interval_ms; /* 30000 in the reference (task_scheduler.rs:44-46) */
     int fused;                   /* 0: Trace fills mapped_photons, Plot splats them (reference structure);
                                     1: Trace renders straight into the plot unit it will be plotted by */
-    const char* output_ppm;      /* written after every tonemap (binary P6); NULL = none.  Replaces output.png (main.rs:61) */
+    const char* output_ppm;      /* image written after every tonemap: "*.png" -> PNG (the reference's output.png,
+                                    main.rs:61), anything else -> binary PPM (P6); NULL = none */
     const char* checkpoint;      /* GatherUnit::save target, written at every tonemap and at the end; NULL = none */
     int resume;                  /* non-zero: rl_gather_unit_load(checkpoint) before rendering (gather_unit.rs:42-43) */
     int verbose;                 /* print the reference's progress lines (task_scheduler.rs:242-325) */

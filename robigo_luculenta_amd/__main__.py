@@ -15,7 +15,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scene", choices=["demo", "glass"], default="demo")
     ap.add_argument("--unfused", action="store_true", help="keep the reference's separate Trace and Plot work")
-    ap.add_argument("--output", default="output.ppm")
+    ap.add_argument("--output", default="output.png", help="*.png or *.ppm")  # main.rs:61
     ap.add_argument("--checkpoint", default=None, help="buffer.raw to write (and to resume from with --resume)")
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("--quiet", action="store_true")

@@ -5,6 +5,7 @@
 // (app.rs:57,107), tasks executed outside the lock, Sleep = 100 ms (app.rs:129).  Differences, all
 // forced by "the reference never terminates and is unseedable": a batch budget (max_batches), a path
 // range per trace task, and explicit checkpoint / image file names.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -48,6 +49,75 @@ void fail(AppState& a, int rc) {
     if (a.error.compare_exchange_strong(expected, rc)) a.error_message = rl_last_error();
 }
 
+// Minimal PNG encoder (RGB8, zlib "stored" blocks, no external library) so the App can write the
+// reference's output.png (main.rs:61) -- the image crate only matters for the file format.
+uint32_t crc32_update(uint32_t crc, const uint8_t* data, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ data[i]) & 0xffu] ^ (crc >> 8);
+    return crc;
+}
+
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+
+void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+    put_be32(out, (uint32_t)data.size());
+    std::vector<uint8_t> body(type, type + 4);
+    body.insert(body.end(), data.begin(), data.end());
+    out.insert(out.end(), body.begin(), body.end());
+    put_be32(out, crc32_update(0xffffffffu, body.data(), body.size()) ^ 0xffffffffu);
+}
+
+int write_png(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> raw; // filter byte 0 + row
+    raw.reserve((size_t)h * (w * 3 + 1));
+    for (uint32_t y = 0; y < h; ++y) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0; // adler32
+    for (size_t i = 0; i < raw.size(); ++i) {
+        a = (a + raw[i]) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)n); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)~n); z.push_back((uint8_t)(~n >> 8));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        pos += n;
+        if (n == 0) break;
+    }
+    put_be32(z, (b << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w);
+    put_be32(ihdr, h);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0}; // 8-bit RGB, deflate, no filter, no interlace
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    png_chunk(out, "IHDR", ihdr);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", std::vector<uint8_t>());
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return RL_E_IO;
+    const size_t written = std::fwrite(out.data(), 1, out.size(), f);
+    return (std::fclose(f) == 0 && written == out.size()) ? RL_OK : RL_E_IO;
+}
+
+int write_image(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h);
+
 int write_ppm(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
     FILE* f = std::fopen(path, "wb");
     if (!f) return RL_E_IO;
@@ -55,6 +125,12 @@ int write_ppm(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
     const size_t n = (size_t)w * h * 3;
     const size_t written = std::fwrite(rgb, 1, n, f);
     return (std::fclose(f) == 0 && written == n) ? RL_OK : RL_E_IO;
+}
+
+int write_image(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
+    const size_t n = std::strlen(path);
+    if (n >= 4 && std::strcmp(path + n - 4, ".png") == 0) return write_png(path, rgb, w, h);
+    return write_ppm(path, rgb, w, h);
 }
 
 // App::execute_task (app.rs:113-126)
@@ -89,7 +165,7 @@ void execute_task(AppState& a, const RlTask& task) {
     case RL_TASK_TONEMAP: // app.rs:154-164
         rc = rl_tonemap_unit_tonemap(a.tonemap, a.gather);
         if (rc == RL_OK) rc = rl_tonemap_unit_rgb(a.tonemap, a.rgb.data());
-        if (rc == RL_OK && c.output_ppm) rc = write_ppm(c.output_ppm, a.rgb.data(), c.width, c.height);
+        if (rc == RL_OK && c.output_ppm) rc = write_image(c.output_ppm, a.rgb.data(), c.width, c.height);
         if (rc == RL_OK && c.checkpoint) rc = rl_gather_unit_save(a.gather, c.checkpoint);
         if (rc == RL_OK && c.verbose && c.output_ppm) std::printf("wrote image to %s\n", c.output_ppm);
         break;

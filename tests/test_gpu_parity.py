@@ -224,6 +224,15 @@ def test_app_worker_pool_renders_the_same_image_as_the_oracle(demo, fused, concu
     data = open(ppm, "rb").read()
     assert data.startswith(b"P6\n%d %d\n255\n" % (W, H)) and data[-W * H * 3:] == rgb.tobytes()
     assert os.path.getsize(raw) == 2 * W * H * 12      # gather_unit.rs:68-78
+    # PNG output (the reference's output.png): decode the stored-deflate stream and compare
+    png = str(tmp_path / "output.png")
+    rgb3, _ = R.app_run(W, H, 0, concurrency=1, photons_per_batch=n, seed=3, checkpoint=raw, resume=True, output_ppm=png)
+    import zlib
+    blob = open(png, "rb").read()
+    assert blob[:8] == b"\x89PNG\r\n\x1a\n" and blob[12:16] == b"IHDR"
+    idat = blob[blob.index(b"IDAT") + 4: blob.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(H, 1 + 3 * W)
+    assert (rows[:, 0] == 0).all() and rows[:, 1:].tobytes() == rgb3.tobytes() == rgb.tobytes()
     # resume from the checkpoint: rendering 0 more batches reproduces the image from buffer.raw alone
     rgb2, st2 = R.app_run(W, H, 0, concurrency=1, photons_per_batch=n, seed=3, checkpoint=raw, resume=True)
     assert st2["batches"] == 0 and rgb2.tobytes() == rgb.tobytes()
