@@ -123,7 +123,10 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
     if (dyn > 64 * 1024)
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    uint64_t blocks = (uint64_t)u->cu_count;
+    int per_cu = 1;
+    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
+    if (per_cu < 1) per_cu = 1;
+    uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
 
