@@ -41,6 +41,7 @@ CONFIGS = {
     "ablate-noprisms": ("demo[:317]", 0, 1920, 1080),
     "ablate-fixed7": ("demo[:7]", 0, 1920, 1080),
     "ablate-seeds": ("demo[:207]", 0, 1920, 1080),
+    "ablate-allgrey": ("demo[grey]", 0, 1920, 1080),  # every reflective material -> DiffuseGrey(0.8)
 }
 
 
@@ -131,6 +132,11 @@ def main():
     scene_name, param, W, H = CONFIGS[args.config]
     which = R.SCENE_DEMO if scene_name.startswith("demo") else R.SCENE_GLASS_STRESS
     objs, cam = R.builtin_scene_desc(which, param)
+    if "[grey]" in scene_name:
+        objs = objs.copy()
+        refl = objs["material_kind"] != 0
+        objs["material_kind"][refl] = 1
+        objs["m"][refl] = (0.8, 0, 0)
     if "[:" in scene_name:
         objs = objs[: int(scene_name.split("[:")[1].rstrip("]"))].copy()
     scene = R.Scene(objs, cam, device=device)

@@ -2,17 +2,20 @@
 // Kahan gather, exposure, tonemap.  Included once by rl_api.hip.
 //
 // Trace kernel design (wave64, CDNA4):
-//   * one live path per lane; a lane whose path ended takes the next path index from its wave's
-//     chunk of a global work queue (one atomic per CHUNK paths per wave) and regenerates its camera
-//     ray, so the intersection scan -- >95 % of the instructions -- always runs with full exec mask
-//     until the queue drains;
-//   * the scene (16-byte records, rl_scene.h) is either staged in LDS by the workgroup and read with
-//     wave-uniform ds_read_b128 broadcasts (RL_FETCH_LDS) or read straight from global memory with
-//     wave-uniform addresses, which the compiler turns into scalar s_load_dwordx4 through the scalar
-//     cache (RL_FETCH_GLOBAL);
+//   * one workgroup of 16 waves per CU stages ONE copy of the scene (16-byte records, rl_scene.h) in
+//     LDS (RL_FETCH_LDS; wave-uniform ds_read_b128 broadcasts) or reads it from global memory with
+//     wave-uniform addresses (RL_FETCH_GLOBAL; automatic when the scene does not fit beside the
+//     per-wave scratch in 160 KB);
+//   * persistent waves, one live path per lane.  Camera rays are generated 64 at a time with a full
+//     exec mask into a per-wave LDS stash; a lane whose path ended pops the next ray from the stash,
+//     so the scan always runs with all lanes busy until the global work queue (one atomic per 256
+//     paths per wave) drains;
+//   * the scan (rl_scan_wave) runs only cheap exact reject tests lane-per-ray; every expensive tail
+//     (sphere roots, cluster members, prism CSG) is compacted with ballot/mbcnt into LDS rings and
+//     evaluated 64 (item, ray) pairs at a time, results min-merged per ray with ds_min_u64;
 //   * results leave either as MappedPhoton records (un-fused, bit-comparable with the CPU) or as
 //     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
-//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue.
+//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (~90 % busy).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -236,3 +236,17 @@ def test_app_worker_pool_renders_the_same_image_as_the_oracle(demo, fused, concu
     # resume from the checkpoint: rendering 0 more batches reproduces the image from buffer.raw alone
     rgb2, st2 = R.app_run(W, H, 0, concurrency=1, photons_per_batch=n, seed=3, checkpoint=raw, resume=True)
     assert st2["batches"] == 0 and rgb2.tobytes() == rgb.tobytes()
+
+
+def test_scene_too_large_for_lds_spills_to_global_fetch():
+    """BASELINE config 5's "LDS-spill / global-HBM primitive path": with 1500 seeds per spiral the scene
+    blob plus the per-wave scratch exceed 160 KB of LDS, so RL_FETCH_LDS silently reads the primitives
+    from HBM/L2 instead -- results must not change."""
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO, 1500)
+    assert len(objs) > 4500
+    scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+    W, H, N = 320, 180, 1 << 13
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    t.render(scene, seed=2, stream=0, first_path_index=0)      # default fetch = LDS, falls back
+    want, segs = oscene.render(W, H, 2, 0, 0, N, threads=8)
+    assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
