@@ -250,3 +250,17 @@ def test_scene_too_large_for_lds_spills_to_global_fetch():
     t.render(scene, seed=2, stream=0, first_path_index=0)      # default fetch = LDS, falls back
     want, segs = oscene.render(W, H, 2, 0, 0, N, threads=8)
     assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
+
+
+@pytest.mark.parametrize("seed", [1, 4, 6])
+def test_random_scenes_bit_exact_on_device(seed):
+    from _random_scene import random_scene
+    objs, cam = random_scene(seed, n_spheres=40 + 30 * seed)
+    scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+    N = 1 << 15
+    for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+        t = R.TraceUnit(0, 320, 180, n_photons=N)
+        t.set_fetch(fetch)
+        t.render(scene, seed=seed, stream=0, first_path_index=0)
+        want, segs = oscene.render(320, 180, seed, 0, 0, N, threads=8)
+        assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs

@@ -80,3 +80,16 @@ def test_plot_weights_and_cie_lookup_bit_exact():
     edge["probability"] = 1.0
     edge["wavelength"] = [380, 780, 379.0, 781.0, 555, 374.9]
     assert M.plot(96, 54, edge).tobytes() == O.plot(96, 54, edge).tobytes()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes_bit_exact(seed):
+    """Culls must stay conservative on arbitrary geometry: overlapping, nested and huge spheres, randomly
+    oriented prisms, glass everywhere (un-normalised directions, material.rs:246)."""
+    from _random_scene import random_scene
+    objs, cam = random_scene(seed, n_spheres=40 + 30 * seed)
+    so, sm = O.Scene(objs, cam), M.Scene(objs, cam)
+    want, segs = so.render(320, 180, seed, 0, 0, 40000, threads=8)
+    got, segs2 = sm.render(320, 180, seed, 0, 0, 40000)
+    assert segs == segs2 and got.tobytes() == want.tobytes()
+    assert (want["probability"] > 0).any()
