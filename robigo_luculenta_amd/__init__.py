@@ -70,6 +70,7 @@ class Scene(_Handle):
     def __init__(self, objects, camera, device=0):
         super().__init__()
         self.objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        camera = RlCameraDesc.from_buffer_copy(bytes(camera))  # accept any 40-byte camera record
         desc = RlSceneDesc(len(self.objects), self.objects.ctypes.data_as(C.c_void_p), camera)
         check(lib.rl_scene_create(C.byref(desc), device, C.byref(self._h)))
         self.device = device
