@@ -83,6 +83,8 @@ struct RlPath {
     float intensity;         // trace_unit.rs:88
     float continue_chance;   // trace_unit.rs:84
     float sx, sy;            // screen position, trace_unit.rs:157-158
+    float ior;               // SF10 index of refraction at `wavelength` (material.rs:203-213): a function of
+                             // the path's wavelength only, so it is evaluated once per path, not per bounce
     uint32_t bounce;         // RNG block = 2 + bounce
 };
 
@@ -93,6 +95,13 @@ struct RlHit {
     uint32_t obj; // object index or RL_HIT_NONE
     uint32_t sub; // prism: which of the 8 half-spaces
 };
+
+// material.rs:203-213
+RL_HD float rl_sf10_ior(float wavelength) {
+    const double w2 = (double)(wavelength * wavelength * 1.0e-6f);
+    return (float)sqrt(1.0 + 1.737596950 * w2 / (w2 - 0.0131887070) + 0.313747346 * w2 / (w2 - 0.0623068142) +
+                       1.898781010 * w2 / (w2 - 155.23629000));
+}
 
 // ---- camera: trace_unit.rs:151-148, app.rs:327-357, camera.rs:47-108 --------------------------
 
@@ -145,6 +154,7 @@ RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t see
     p->continue_chance = 1.0f;
     p->sx = x;
     p->sy = y;
+    p->ior = rl_sf10_ior(wavelength);
     p->bounce = 0;
 }
 
@@ -386,12 +396,6 @@ RL_HD float rl_black_body_normalisation(float kelvins, float intensity) {
     const double wien = 2.897772126e-3; // constants.rs:25
     return intensity / (float)rl_boltzmann((wien / (double)kelvins) * 1.0e9, (double)kelvins);
 }
-// material.rs:203-213
-RL_HD float rl_sf10_ior(float wavelength) {
-    const double w2 = (double)(wavelength * wavelength * 1.0e-6f);
-    return (float)sqrt(1.0 + 1.737596950 * w2 / (w2 - 0.0131887070) + 0.313747346 * w2 / (w2 - 0.0623068142) +
-                       1.898781010 * w2 / (w2 - 155.23629000));
-}
 RL_HD float rl_clamp999(float x) { // material.rs:288-292
     if (x < -0.999f) return -0.999f;
     if (x > 0.999f) return 0.999f;
@@ -424,7 +428,7 @@ RL_HD bool rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint
 
     if (material_kind == RL_MATERIAL_SF10_GLASS) { // material.rs:216-260
         float cos_i = -rl_dot(in_dir, is.normal);
-        float ior = rl_sf10_ior(p->wavelength);
+        float ior = p->ior;
         RlF3 normal = is.normal;
         if (cos_i > 0.0f) {
             ior = 1.0f / ior;

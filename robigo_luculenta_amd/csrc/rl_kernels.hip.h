@@ -63,9 +63,9 @@ struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
-    // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy, then the
-    // path's offset in the launch (lo, hi; ~0 = no path).  Refilled with all 64 lanes busy.
-    float stash[9][64];
+    // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior, then
+    // the path's offset in the launch (lo, hi; ~0 = no path).  Refilled with all 64 lanes busy.
+    float stash[10][64];
     uint32_t stash_off[2][64];
 };
 
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     p.intensity = 0.0f;
     p.continue_chance = 0.0f;
     p.sx = p.sy = 0.0f;
+    p.ior = 1.0f;
     p.bounce = 0;
     uint32_t segments = 0, paths_done = 0;
 
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 stash[6 * 64 + lane] = fresh.wavelength;
                 stash[7 * 64 + lane] = fresh.sx;
                 stash[8 * 64 + lane] = fresh.sy;
+                stash[9 * 64 + lane] = fresh.ior;
                 stash_off[lane] = valid ? (uint32_t)offset : 0xffffffffu;
                 stash_off[64 + lane] = valid ? (uint32_t)(offset >> 32) : 0xffffffffu;
                 rl_wave_sync();
@@ -396,6 +398,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     p.wavelength = stash[6 * 64 + slot];
                     p.sx = stash[7 * 64 + slot];
                     p.sy = stash[8 * 64 + slot];
+                    p.ior = stash[9 * 64 + slot];
                     p.intensity = 1.0f;
                     p.continue_chance = 1.0f;
                     p.bounce = 0;
