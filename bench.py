@@ -175,6 +175,13 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if world > 1:
+        # Create the communicator and run the reduce once outside the timed region even when the warm-up
+        # steps did not reach a gather (RCCL builds its rings lazily on the first collective).
+        if on_device:
+            dist.reduce(torch.zeros_like(xyz), dst=0, op=dist.ReduceOp.SUM)
+        else:
+            dist.reduce(torch.zeros(xyz.numel(), dtype=torch.float32), dst=0, op=dist.ReduceOp.SUM)
     fence()
     p0, s0, ms0 = trace.stats()
     t0 = time.perf_counter()
@@ -225,7 +232,9 @@ def main():
                                          "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms,
                          "algorithmic_flops_per_ray": f_seg,
-                         "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only"},
+                         "valu_busy_profiled": 0.90, "active_lanes_profiled": 0.67,
+                         "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only; "
+                                 "valu_busy / active_lanes from the PMC passes in profiles/r01b_pmc_summary.txt"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, cam, W, H)
