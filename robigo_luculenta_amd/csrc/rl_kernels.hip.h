@@ -58,6 +58,20 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// rl_bound_pass() as ONE integer compare, for the wave-uniform cull loops (a compound float condition
+// would be materialised lane by lane before the ballot).  With u = (d.co)^2 - c s, s = 0.999 |d|^2:
+//   pass  <=>  (c <= 0 || (d.co > 0 && u >= 0))  <=>  u >= 0 && !(c > 0 && d.co <= 0)
+// (c <= 0 implies u >= 0).  On the sign bits: bits(u) | ((0 - bits(c)) & (bits(d.co) - 1)) has its
+// sign bit clear.  The integer forms only differ from the float compares for -0 and NaN inputs, where
+// they pass (a superset is always safe for a cull).
+__device__ __forceinline__ bool rl_bound_pass_bits(RlF4 b, RlF3 o, RlF3 dir, float dlen2_scaled, uint32_t disable_bit) {
+    const float cox = b.x - o.x, coy = b.y - o.y, coz = b.z - o.z;
+    const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
+    const float c = (cox * cox + coy * coy + coz * coz) - b.w;
+    const float u = dd * dd - c * dlen2_scaled;
+    return (int)(rl_f2u(u) | ((0u - rl_f2u(c)) & (rl_f2u(dd) - 1u)) | disable_bit) >= 0;
+}
+
 // Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
 struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
@@ -70,7 +84,8 @@ struct RlWaveScratch {
 };
 
 // Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
-// uniform control flow (`active` masks the lanes without a path; such lanes carry dir = 0).
+// uniform control flow.  `idle_bit` is 0x80000000 on lanes without a path (0 otherwise); it is OR-ed into
+// the integer reject/cull compares so such lanes never enqueue work (they also carry dir = 0).
 //
 // Every ray is tested against wave-uniform records (LDS broadcast or scalar loads) only up to a cheap
 // reject test; expensive tails never run under divergence.  The (item, ray) pairs that survive are
@@ -85,7 +100,7 @@ struct RlWaveScratch {
 //     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, bool active, RlWaveScratch* ws,
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
@@ -155,13 +170,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
     // Reject test of one sphere record S for the ray (OX.., DX..); survivors go to ring B as
     // (POS << 6) | OWNER.  The integer compare is a superset of (q >= 0 && d.co > 0) on the sign
     // bits; the ring-B round re-evaluates the exact float conditions.
-#define RL_SPHERE_REJECT(S, POS, OWNER, ENABLE, OX, OY, OZ, DX, DY, DZ)                             \
+#define RL_SPHERE_REJECT(S, POS, OWNER, DISABLE_BIT, OX, OY, OZ, DX, DY, DZ)                        \
     {                                                                                               \
         const float cox = (S).x - (OX), coy = (S).y - (OY), coz = (S).z - (OZ);                     \
         const float dd = (DX) * cox + (DY) * coy + (DZ) * coz;                                      \
         const float c = (cox * cox + coy * coy + coz * coz) - (S).w;                                \
         const float q = dd * dd - c;                                                                \
-        const bool cand = ENABLE((int)(rl_f2u(q) | (rl_f2u(dd) - 1u)) >= 0);                        \
+        const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u) | (DISABLE_BIT)) >= 0;               \
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
         if (m != 0) {                                                                               \
             if (cand) ring_b[(b_tail + rl_mbcnt(m)) & 127u] = ((POS) << 6) | (OWNER);               \
@@ -172,17 +187,16 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
             }                                                                                       \
         }                                                                                           \
     }
-#define RL_ALWAYS(X) (X)
 
     // ---- direct spheres: every ray against every record, unrolled by 4 with one group of prefetch ----
     if (sv.n_direct != 0) {
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
         for (uint32_t i = 0; i < sv.n_direct_padded; i += 4) {
             const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // padded
-            RL_SPHERE_REJECT(c0, i, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
-            RL_SPHERE_REJECT(c1, i + 1, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
-            RL_SPHERE_REJECT(c2, i + 2, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
-            RL_SPHERE_REJECT(c3, i + 3, lane, RL_ALWAYS, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c1, i + 1, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c2, i + 2, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            RL_SPHERE_REJECT(c3, i + 3, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
     }
@@ -192,20 +206,21 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         rl_wave_sync();
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
-        const uint32_t first = sv.cluster_base + RL_CLUSTER_STRIDE * (e >> 6) + 1u;
+        // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
+        const uint32_t first = sv.cluster_base + RL_CLUSTER_STRIDE * (lane < count ? (e >> 6) : 0u) + 1u;
         const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
         const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
-        const bool mine = lane < count;
-#define RL_IF_MINE(X) (mine && (X))
-#pragma unroll 2
+        const uint32_t not_mine = lane < count ? 0u : 0x80000000u; // lanes beyond the round never push
+        RlF4 s = sph[first];
         for (uint32_t j = 0; j < RL_CLUSTER_K; ++j) {
-            const RlF4 s = sph[first + j];
-            RL_SPHERE_REJECT(s, first + j, owner, RL_IF_MINE, ox, oy, oz, dx, dy, dz)
+            const RlF4 s_next = sph[first + (j + 1 < RL_CLUSTER_K ? j + 1 : j)]; // one record of prefetch
+            RL_SPHERE_REJECT(s, first + j, owner, not_mine, ox, oy, oz, dx, dy, dz)
+            s = s_next;
         }
-#undef RL_IF_MINE
         rl_wave_sync();
     };
 
+    const float dlen2_scaled = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f; // see rl_bound_pass
     // ---- sphere clusters: bound cull per ray -> ring A ----
     if (sv.n_clusters != 0) {
         const uint32_t last = sv.cluster_base + RL_CLUSTER_STRIDE * (sv.n_clusters - 1u);
@@ -214,7 +229,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         for (uint32_t k = 0; k < sv.n_clusters; ++k) {
             const uint32_t next = at + RL_CLUSTER_STRIDE;
             const RlF4 nb = sph[next <= last ? next : last]; // prefetch the next bound
-            const bool pass = active && rl_bound_pass(b, o, dir);
+            const bool pass = rl_bound_pass_bits(b, o, dir, dlen2_scaled, idle_bit);
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
             if (m != 0) {
                 if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (k << 6) | lane;
@@ -231,7 +246,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         a_head = a_tail;
     }
 #undef RL_SPHERE_REJECT
-#undef RL_ALWAYS
     if (b_tail != b_head) process_spheres(b_tail - b_head);
     b_head = b_tail;
 
@@ -261,7 +275,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
     };
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4 b = sv.prisms[RL_PRISM_STRIDE * i + 16];
-        const bool pass = active && rl_bound_pass(b, o, dir);
+        const bool pass = rl_bound_pass_bits(b, o, dir, dlen2_scaled, idle_bit);
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
             if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
@@ -336,8 +350,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     bool active = false;
     uint64_t my_offset = 0;
     RlPath p;
-    p.origin = rl_f3(0.0f, 0.0f, 0.0f);
-    p.direction = rl_f3(0.0f, 0.0f, 0.0f); // a lane without a path scans with d = 0: never a sphere candidate
+    p.origin = rl_f3(0.0f, 0.0f, 0.0f); // a lane without a path scans a null ray; rl_scan_wave's idle_bit mutes it
+    p.direction = rl_f3(0.0f, 0.0f, 0.0f);
     p.wavelength = 0.0f;
     p.intensity = 0.0f;
     p.continue_chance = 0.0f;
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             stash_head += wanted < avail ? wanted : avail;
         }
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active, ws, lane);
+        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active ? 0u : 0x80000000u, ws, lane);
         if (active) {
             segments += 1;
             float value;
