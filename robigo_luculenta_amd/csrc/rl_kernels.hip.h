@@ -273,8 +273,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }
         rl_wave_sync();
     };
+    RlF4 pb = sv.prisms[16];
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
-        const RlF4 b = sv.prisms[RL_PRISM_STRIDE * i + 16];
+        const RlF4 b = pb;
+        pb = sv.prisms[RL_PRISM_STRIDE * (i + 1 < sv.n_prisms ? i + 1 : i) + 16]; // prefetch the next bound
         const bool pass = rl_bound_pass_bits(b, o, dir, dlen2_scaled, idle_bit);
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
