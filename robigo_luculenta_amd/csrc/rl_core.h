@@ -198,18 +198,18 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     return -1.0f;
 }
 
-// One candidate of a Compound: distance and which half-space, t < 0 = None.
+// One candidate of a Compound: distance and which half-space.  Inside rl_hex_prism "None" is
+// t = +infinity, which makes Compound::intersect's selection a single compare; the function returns
+// t < 0 for None.
 struct RlCand {
     float t;
     uint32_t k;
 };
 
 // Compound::intersect's selection (geometry.rs:386-399) given both children's (already filtered)
-// candidates: nearest wins, tie -> second child.
+// candidates: nearest wins, tie -> second child; None = +inf loses against anything.
 RL_HD RlCand rl_compound_pick(RlCand a, RlCand b) {
-    // Field-wise selects (selecting whole structs makes the compiler spill both to scratch).
-    const bool a_some = a.t >= 0.0f, b_some = b.t >= 0.0f;
-    const bool take_a = (a_some && b_some) ? (a.t < b.t) : a_some;
+    const bool take_a = a.t < b.t;
     RlCand r;
     r.t = take_a ? a.t : b.t;
     r.k = take_a ? a.k : b.k;
@@ -218,8 +218,9 @@ RL_HD RlCand rl_compound_pick(RlCand a, RlCand b) {
 
 // HexagonalPrism = Compound<InfinitePrism[0,1,2], Compound<InfinitePrism[3,4,5], ThickPlane[6,7]>>
 // with InfinitePrism[a,b,c] = Compound<Compound<a,b>,c> (geometry.rs:409-416).  pr points at the
-// prism's 16 records.
+// prism's 16 half-space records.
 RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
+    const float NONE = __builtin_inff();
     RlF3 n[8], off[8];
     float t[8];
 #if defined(__HIPCC__)
@@ -229,12 +230,13 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
         n[k] = rl_xyz(pr[2 * k]);
         off[k] = rl_xyz(pr[2 * k + 1]);
         float dn;
-        t[k] = rl_plane_t(n[k], off[k], o, dir, &dn);
+        const float tk = rl_plane_t(n[k], off[k], o, dir, &dn);
+        t[k] = tk > 0.0f ? tk : NONE;
     }
     // A candidate of half-space k survives a filter against the set `mask` when its position lies
-    // inside every half-space of the set.
+    // inside every half-space of the set (Compound::intersect's lies_inside filters, geometry.rs:383-384).
     auto filt = [&](RlCand c, uint32_t mask) -> RlCand {
-        if (c.t < 0.0f) return c;
+        if (!(c.t < NONE)) return c;
         const RlF3 pos = rl_add(o, rl_mul(dir, c.t));
         bool in = true;
 #if defined(__HIPCC__)
@@ -242,7 +244,7 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
 #endif
         for (int j = 0; j < 8; ++j)
             if (mask & (1u << j)) in = in && rl_inside(n[j], off[j], pos);
-        if (!in) c.t = -1.0f;
+        if (!in) c.t = NONE;
         return c;
     };
     auto leaf = [&](int k) -> RlCand {
@@ -259,7 +261,9 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     const RlCand ip_main = inf_prism(3, 4, 5);
     const RlCand thick = rl_compound_pick(filt(leaf(6), 1u << 7), filt(leaf(7), 1u << 6));
     const RlCand prism = rl_compound_pick(filt(ip_main, 0xC0u), filt(thick, 0x38u));
-    return rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
+    RlCand hit = rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
+    if (!(hit.t < NONE)) hit.t = -1.0f;
+    return hit;
 }
 
 // Conservative cull (not in the reference) for a hexagonal prism or a sphere cluster: a valid hit
