@@ -222,26 +222,33 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
 
     const float dlen2_scaled = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f; // see rl_bound_pass
     // ---- sphere clusters: bound cull per ray -> ring A ----
-    if (sv.n_clusters != 0) {
-        const uint32_t last = sv.cluster_base + RL_CLUSTER_STRIDE * (sv.n_clusters - 1u);
+    if (sv.n_clusters != 0) { // even count (rl_scene.cpp pads), two clusters per iteration
+        const uint32_t last = sv.cluster_base + RL_CLUSTER_STRIDE * (sv.n_clusters - 2u);
         uint32_t at = sv.cluster_base;
-        RlF4 b = sph[at];
-        for (uint32_t k = 0; k < sv.n_clusters; ++k) {
-            const uint32_t next = at + RL_CLUSTER_STRIDE;
-            const RlF4 nb = sph[next <= last ? next : last]; // prefetch the next bound
-            const bool pass = rl_bound_pass_bits(b, o, dir, dlen2_scaled, idle_bit);
-            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
-            if (m != 0) {
-                if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (k << 6) | lane;
-                a_tail += (uint32_t)__popcll(m);
-                if (a_tail - a_head >= 64u) {
-                    process_clusters(64u);
-                    a_head += 64u;
-                }
-            }
-            at = next;
-            b = nb;
+        RlF4 b0 = sph[at], b1 = sph[at + RL_CLUSTER_STRIDE];
+#define RL_CLUSTER_CULL(B, K)                                                                       \
+    {                                                                                               \
+        const bool pass = rl_bound_pass_bits(B, o, dir, dlen2_scaled, idle_bit);                    \
+        const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
+        if (m != 0) {                                                                               \
+            if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((K) << 6) | lane;                    \
+            a_tail += (uint32_t)__popcll(m);                                                        \
+            if (a_tail - a_head >= 64u) {                                                           \
+                process_clusters(64u);                                                              \
+                a_head += 64u;                                                                      \
+            }                                                                                       \
+        }                                                                                           \
+    }
+        for (uint32_t k = 0; k < sv.n_clusters; k += 2) {
+            const uint32_t next = at + 2 * RL_CLUSTER_STRIDE <= last ? at + 2 * RL_CLUSTER_STRIDE : last;
+            const RlF4 n0 = sph[next], n1 = sph[next + RL_CLUSTER_STRIDE]; // prefetch the next two bounds
+            RL_CLUSTER_CULL(b0, k)
+            RL_CLUSTER_CULL(b1, k + 1)
+            at += 2 * RL_CLUSTER_STRIDE;
+            b0 = n0;
+            b1 = n1;
         }
+#undef RL_CLUSTER_CULL
         if (a_tail != a_head) process_clusters(a_tail - a_head);
         a_head = a_tail;
     }

@@ -470,5 +470,12 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         }
     }
     fs.n_clusters = (uint32_t)clusters.size();
+    // The kernel walks the clusters two at a time: pad to an even count with a cluster that can not
+    // be reached (bound radius^2 = -inf fails every cull) and holds only dummies.
+    if (fs.n_clusters & 1u) {
+        fs.spheres.resize(fs.spheres.size() + RL_CLUSTER_STRIDE, dummy);
+        fs.sphere_obj.resize(fs.spheres.size(), RL_HIT_NONE);
+        fs.n_clusters += 1;
+    }
     return RL_OK;
 }

@@ -56,7 +56,7 @@ struct RlSceneView {
     uint32_t n_direct;         // direct spheres: records [0, n_direct)
     uint32_t n_direct_padded;  // multiple of 4; records [n_direct, n_direct_padded + 4) are dummies
     uint32_t cluster_base;     // first cluster record (= n_direct_padded + 4)
-    uint32_t n_clusters;       // each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
+    uint32_t n_clusters;       // even; each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
     RlCameraDesc camera;
     float screen_distance; // 1 / tan(field_of_view / 2), camera.rs:56 (constant per scene)
 };
