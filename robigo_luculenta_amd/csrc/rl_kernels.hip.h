@@ -65,10 +65,11 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
 // sign bit clear.  The integer forms only differ from the float compares for -0 and NaN inputs, where
 // they pass (a superset is always safe for a cull).
 __device__ __forceinline__ bool rl_bound_pass_bits(RlF4 b, RlF3 o, RlF3 dir, float dlen2_scaled, uint32_t disable_bit) {
+    // The cull is the build's own (conservative) test, not reference arithmetic, so it may use FMA.
     const float cox = b.x - o.x, coy = b.y - o.y, coz = b.z - o.z;
-    const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
-    const float c = (cox * cox + coy * coy + coz * coz) - b.w;
-    const float u = dd * dd - c * dlen2_scaled;
+    const float dd = __builtin_fmaf(dir.z, coz, __builtin_fmaf(dir.y, coy, dir.x * cox));
+    const float c = __builtin_fmaf(coz, coz, __builtin_fmaf(coy, coy, cox * cox)) - b.w;
+    const float u = __builtin_fmaf(dd, dd, -(c * dlen2_scaled));
     return (int)(rl_f2u(u) | ((0u - rl_f2u(c)) & (rl_f2u(dd) - 1u)) | disable_bit) >= 0;
 }
 
