@@ -264,3 +264,21 @@ def test_random_scenes_bit_exact_on_device(seed):
         t.render(scene, seed=seed, stream=0, first_path_index=0)
         want, segs = oscene.render(320, 180, seed, 0, 0, N, threads=8)
         assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
+
+
+def test_cpp_client_of_the_c_abi_renders_a_png(tmp_path):
+    """examples/render.cpp: main.rs as a compiled client that links only against the C ABI."""
+    import subprocess
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True)
+    out = str(tmp_path / "output.png")
+    r = subprocess.run([exe, "2", "128", "72", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "wrote image" in r.stdout
+    blob = open(out, "rb").read()
+    idat = blob[blob.index(b"IDAT") + 4: blob.index(b"IEND") - 8]
+    rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(72, 1 + 3 * 128)
+    assert rows[:, 1:].mean() > 5   # an image, not a black frame
