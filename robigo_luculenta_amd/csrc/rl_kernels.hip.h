@@ -189,16 +189,23 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }                                                                                           \
     }
 
-    // ---- direct spheres: every ray against every record, unrolled by 4 with one group of prefetch ----
+    // ---- direct spheres: every ray against every record; groups of 4 with one group of prefetch, then
+    // the remainder one by one (the padding of rl_scene.h keeps every prefetch in bounds) ----
     if (sv.n_direct != 0) {
+        const uint32_t full = sv.n_direct & ~3u;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
-        for (uint32_t i = 0; i < sv.n_direct_padded; i += 4) {
-            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7]; // padded
+        for (uint32_t i = 0; i < full; i += 4) {
+            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
             RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             RL_SPHERE_REJECT(c1, i + 1, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             RL_SPHERE_REJECT(c2, i + 2, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             RL_SPHERE_REJECT(c3, i + 3, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        for (uint32_t i = full; i < sv.n_direct; ++i) {
+            const RlF4 next = sph[i + 1];
+            RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            c0 = next;
         }
     }
 
