@@ -217,6 +217,8 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_parabs = append(fs.parabs);
     lay.off_prisms = append(fs.prisms);
     lay.off_objects = append(fs.objects);
+    lay.off_cull = append(fs.cull_bounds);
+    lay.cull_cmax2 = fs.cull_cmax2;
     lay.off_cie = (uint32_t)blob.size();
     const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
     blob.insert(blob.end(), cie, cie + RL_CIE_SAMPLES);

@@ -28,7 +28,8 @@
 
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
-    uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cie, off_sphere_obj, total_f4;
+    uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cull, off_cie, off_sphere_obj, total_f4;
+    float cull_cmax2; // RlFlatScene::cull_cmax2
     uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
     RlCameraDesc camera;
     float screen_distance;
@@ -58,19 +59,39 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-// rl_bound_pass() as ONE integer compare, for the wave-uniform cull loops (a compound float condition
-// would be materialised lane by lane before the ballot).  With u = (d.co)^2 - c s, s = 0.999 |d|^2:
-//   pass  <=>  (c <= 0 || (d.co > 0 && u >= 0))  <=>  u >= 0 && !(c > 0 && d.co <= 0)
-// (c <= 0 implies u >= 0).  On the sign bits: bits(u) | ((0 - bits(c)) & (bits(d.co) - 1)) has its
-// sign bit clear.  The integer forms only differ from the float compares for -0 and NaN inputs, where
-// they pass (a superset is always safe for a cull).
-__device__ __forceinline__ bool rl_bound_pass_bits(RlF4 b, RlF3 o, RlF3 dir, float dlen2_scaled, uint32_t disable_bit) {
-    // The cull is the build's own (conservative) test, not reference arithmetic, so it may use FMA.
-    const float cox = b.x - o.x, coy = b.y - o.y, coz = b.z - o.z;
-    const float dd = __builtin_fmaf(dir.z, coz, __builtin_fmaf(dir.y, coy, dir.x * cox));
-    const float c = __builtin_fmaf(coz, coz, __builtin_fmaf(coy, coy, cox * cox)) - b.w;
-    const float u = __builtin_fmaf(dd, dd, -(c * dlen2_scaled));
-    return (int)(rl_f2u(u) | ((0u - rl_f2u(c)) & (rl_f2u(dd) - 1u)) | disable_bit) >= 0;
+// The conservative cull of rl_bound_pass() for the wave-uniform loops, in expanded form so that
+// everything ray-dependent is hoisted out of the loop (8 FMAs + 5 integer ops per bound):
+//   d.(c - o)          = d.c + P,                    P = -d.o
+//   s (|c - o|^2 - R^2) = s w - 2 s o.c + s |o|^2,    w = |c|^2 - R^2 (table), s = 0.999 |d|^2
+//   u = (d.co)^2 - s (|co|^2 - R^2);  pass <=> u >= 0 && !(c > 0 && d.co <= 0)
+// evaluated on the sign bits with one integer compare (a compound float condition would be
+// materialised lane by lane before the ballot).  The expansion cancels, so the |o|^2 term carries a
+// slack of 1e-5 (|o|^2 + max|c|^2) -- more than 40x the worst rounding error 4 eps (|o|^2 + |c|^2) of
+// either product sum at any scene scale -- which only ever lets MORE pairs through.  This is the
+// build's own test (not reference arithmetic), so FMA is fine; -0/NaN inputs pass (a superset is safe).
+struct RlCullRay {
+    RlF3 d;       // direction
+    float p;      // -d.o
+    RlF3 m;       // -2 s o
+    float s, q;   // s, s (|o|^2 - slack)
+    uint32_t idle_bit;
+};
+__device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, uint32_t idle_bit) {
+    RlCullRay r;
+    r.d = dir;
+    r.p = -(dir.x * o.x + dir.y * o.y + dir.z * o.z);
+    r.s = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f;
+    const float o2 = o.x * o.x + o.y * o.y + o.z * o.z;
+    r.m = rl_f3(-2.0f * r.s * o.x, -2.0f * r.s * o.y, -2.0f * r.s * o.z);
+    r.q = r.s * (o2 - 1.0e-5f * (o2 + cmax2));
+    r.idle_bit = idle_bit;
+    return r;
+}
+__device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b) {
+    const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
+    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, __builtin_fmaf(r.s, b.w, r.q))));
+    const float u = __builtin_fmaf(dd, dd, -cs);
+    return (int)(rl_f2u(u) | ((0u - rl_f2u(cs)) & (rl_f2u(dd) - 1u)) | r.idle_bit) >= 0;
 }
 
 // Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
@@ -101,8 +122,8 @@ struct RlWaveScratch {
 //     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
-                                              uint32_t lane) {
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2, RlF3 o, RlF3 dir,
+                                              uint32_t idle_bit, RlWaveScratch* ws, uint32_t lane) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
     RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
@@ -228,15 +249,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         rl_wave_sync();
     };
 
-    const float dlen2_scaled = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f; // see rl_bound_pass
+    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit);
     // ---- sphere clusters: bound cull per ray -> ring A ----
     if (sv.n_clusters != 0) { // even count (rl_scene.cpp pads), two clusters per iteration
-        const uint32_t last = sv.cluster_base + RL_CLUSTER_STRIDE * (sv.n_clusters - 2u);
-        uint32_t at = sv.cluster_base;
-        RlF4 b0 = sph[at], b1 = sph[at + RL_CLUSTER_STRIDE];
+        RlF4 b0 = cull[0], b1 = cull[1];
 #define RL_CLUSTER_CULL(B, K)                                                                       \
     {                                                                                               \
-        const bool pass = rl_bound_pass_bits(B, o, dir, dlen2_scaled, idle_bit);                    \
+        const bool pass = rl_cull_pass(cr, B);                                                      \
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
         if (m != 0) {                                                                               \
             if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((K) << 6) | lane;                    \
@@ -248,11 +267,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }                                                                                           \
     }
         for (uint32_t k = 0; k < sv.n_clusters; k += 2) {
-            const uint32_t next = at + 2 * RL_CLUSTER_STRIDE <= last ? at + 2 * RL_CLUSTER_STRIDE : last;
-            const RlF4 n0 = sph[next], n1 = sph[next + RL_CLUSTER_STRIDE]; // prefetch the next two bounds
+            const RlF4 n0 = cull[k + 2], n1 = cull[k + 3]; // prefetch (the table has slack at its end)
             RL_CLUSTER_CULL(b0, k)
             RL_CLUSTER_CULL(b1, k + 1)
-            at += 2 * RL_CLUSTER_STRIDE;
             b0 = n0;
             b1 = n1;
         }
@@ -288,11 +305,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, RlF3 o, RlF
         }
         rl_wave_sync();
     };
-    RlF4 pb = sv.prisms[16];
+    const RlF4* pcull = cull + sv.n_clusters;
+    RlF4 pb = pcull[0];
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4 b = pb;
-        pb = sv.prisms[RL_PRISM_STRIDE * (i + 1 < sv.n_prisms ? i + 1 : i) + 16]; // prefetch the next bound
-        const bool pass = rl_bound_pass_bits(b, o, dir, dlen2_scaled, idle_bit);
+        pb = pcull[i + 1]; // prefetch (slack record at the end of the table)
+        const bool pass = rl_cull_pass(cr, b);
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
             if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
@@ -440,7 +458,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             stash_head += wanted < avail ? wanted : avail;
         }
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        const RlHit hit = rl_scan_wave(sv, p.origin, p.direction, active ? 0u : 0x80000000u, ws, lane);
+        const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, p.origin, p.direction,
+                                       active ? 0u : 0x80000000u, ws, lane);
         if (active) {
             segments += 1;
             float value;

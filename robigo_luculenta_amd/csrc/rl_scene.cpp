@@ -477,5 +477,17 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         fs.sphere_obj.resize(fs.spheres.size(), RL_HIT_NONE);
         fs.n_clusters += 1;
     }
+    // Cull table for the kernel: {c, |c|^2 - R^2} per cluster bound, then per prism bound.
+    fs.cull_cmax2 = 0.0f;
+    auto add_bound = [&](const RlF4& b) {
+        const double c2 = (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z;
+        RlF4 r = b;
+        r.w = (float)(c2 - (double)b.w); // -inf radius^2 (dummy) -> +inf: never reached; +inf (unbounded) -> -inf: always
+        fs.cull_bounds.push_back(r);
+        if (std::isfinite(b.w)) fs.cull_cmax2 = std::max(fs.cull_cmax2, (float)c2 * 1.0001f);
+    };
+    for (uint32_t k = 0; k < fs.n_clusters; ++k) add_bound(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
+    for (size_t i = 0; i < fs.prisms.size() / RL_PRISM_STRIDE; ++i) add_bound(fs.prisms[RL_PRISM_STRIDE * i + 16]);
+    fs.cull_bounds.push_back(dummy); // one record of slack for the kernel's prefetch
     return RL_OK;
 }

@@ -64,13 +64,17 @@ struct RlSceneView {
 // Host-side flattened scene (built once by rl_scene_create).
 struct RlFlatScene {
     std::vector<RlF4> spheres, planes, parabs, prisms, objects;
+    // Device-only copy of every bound, clusters first then prisms, as {centre.xyz, |centre|^2 - radius^2}:
+    // the form the kernel's expanded cull test consumes (rl_kernels.hip.h), contiguous for uniform fetches.
+    std::vector<RlF4> cull_bounds;
+    float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView
     RlCameraDesc camera;
     float screen_distance;
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).
     size_t staged_bytes() const {
-        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size()) * sizeof(RlF4) +
+        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size()) * sizeof(RlF4) +
                sphere_obj.size() * sizeof(uint32_t);
     }
 };
