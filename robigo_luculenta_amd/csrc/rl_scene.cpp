@@ -437,7 +437,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         }
         const bool use_clusters = sph_in.size() >= 4 * RL_CLUSTER_K;
         for (uint32_t k = 0; k < sph_in.size(); ++k) {
-            if (!use_clusters || sph_in[k].radius > 2.5 * median || !std::isfinite(sph_in[k].radius)) direct.push_back(k);
+            if (!use_clusters || sph_in[k].radius > 4.0 * median || !std::isfinite(sph_in[k].radius)) direct.push_back(k);
             else clustered.push_back(k);
         }
     }
