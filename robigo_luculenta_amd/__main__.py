@@ -9,7 +9,10 @@ def main():
     ap = argparse.ArgumentParser(prog="python -m robigo_luculenta_amd")
     ap.add_argument("--width", type=int, default=1280)    # main.rs:47
     ap.add_argument("--height", type=int, default=720)    # main.rs:48
-    ap.add_argument("--batches", type=int, default=512, help="trace batches of 524288 paths (the reference runs forever)")
+    ap.add_argument("--batches", type=int, default=32, help="trace tasks to run (the reference runs forever)")
+    ap.add_argument("--photons-per-batch", type=int, default=64 * 1024 * 512,
+                    help="paths per trace task; the reference's 524288 (trace_unit.rs:67) keeps an MI355X busy for "
+                         "0.2 ms only, so the default is 64 of those")
     ap.add_argument("--concurrency", type=int, default=2)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed", type=int, default=1)
@@ -22,11 +25,12 @@ def main():
     a = ap.parse_args()
     print("rendering %d batches at %dx%d" % (a.batches, a.width, a.height))
     rgb, st = app_run(a.width, a.height, a.batches, concurrency=a.concurrency, device=a.device, seed=a.seed,
+                      photons_per_batch=a.photons_per_batch,
                       scene=SCENE_DEMO if a.scene == "demo" else SCENE_GLASS_STRESS, fused=not a.unfused,
                       output_ppm=a.output, checkpoint=a.checkpoint, resume=a.resume, verbose=not a.quiet)
-    print("%d batches, %.1f Mpaths, %.1f Mrays in %.2f s (%.1f Mrays/s, %.1f batches/sec); wrote %s"
+    print("%d trace tasks, %.1f Mpaths, %.1f Mrays in %.2f s (%.1f Mrays/s, %.1f reference batches/sec); wrote %s"
           % (st["batches"], st["paths"] / 1e6, st["segments"] / 1e6, st["seconds"], st["segments"] / st["seconds"] / 1e6,
-             st["batches"] / st["seconds"], a.output))
+             st["paths"] / 524288.0 / st["seconds"], a.output))
 
 
 if __name__ == "__main__":

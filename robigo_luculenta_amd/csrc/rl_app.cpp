@@ -151,12 +151,11 @@ void execute_task(AppState& a, const RlTask& task) {
             for (uint32_t i = 0; i < task.n_units; ++i) units.push_back(a.trace_units[task.units[i]]);
             rc = rl_plot_unit_plot(a.plot_units[task.unit], units.data(), (uint32_t)units.size());
         } else {
-            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) {
-                RlTraceUnit* t = a.trace_units[task.units[i]];
-                rc = rl_trace_unit_render_fused(t, a.scene, a.plot_units[task.unit], c.seed, c.stream,
+            // every unit renders on its own stream: launch them all, then wait for all
+            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i)
+                rc = rl_trace_unit_render_fused(a.trace_units[task.units[i]], a.scene, a.plot_units[task.unit], c.seed, c.stream,
                                                 a.trace_first_path[task.units[i]], a.photons);
-                if (rc == RL_OK) rc = rl_trace_unit_sync(t);
-            }
+            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) rc = rl_trace_unit_sync(a.trace_units[task.units[i]]);
         }
         break;
     case RL_TASK_GATHER: // app.rs:143-152 (save moved to tonemap time)
