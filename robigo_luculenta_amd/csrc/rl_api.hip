@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -159,9 +160,23 @@ unsigned grid_for(uint64_t work_items, int cu_count) {
 }
 
 int cu_count_of(int device, int* out) {
+    // hipGetDeviceProperties is slow; the answer never changes, so remember it per device.
+    static std::mutex lock;
+    static int cached[64];
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> guard(lock);
+        if (cached[device] > 0) {
+            *out = cached[device];
+            return RL_OK;
+        }
+    }
     hipDeviceProp_t prop;
     RL_HIP(hipGetDeviceProperties(&prop, device));
     *out = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (device >= 0 && device < 64) {
+        std::lock_guard<std::mutex> guard(lock);
+        cached[device] = *out;
+    }
     return RL_OK;
 }
 

@@ -60,38 +60,37 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
 }
 
 // The conservative cull of rl_bound_pass() for the wave-uniform loops, in expanded form so that
-// everything ray-dependent is hoisted out of the loop (8 FMAs + 5 integer ops per bound):
-//   d.(c - o)          = d.c + P,                    P = -d.o
+// everything ray-dependent is hoisted out of the loop (9 float ops + one compare per bound):
+//   d.(c - o)           = d.c + P,                    P = -d.o
 //   s (|c - o|^2 - R^2) = s w - 2 s o.c + s |o|^2,    w = |c|^2 - R^2 (table), s = 0.999 |d|^2
-//   u = (d.co)^2 - s (|co|^2 - R^2);  pass <=> u >= 0 && !(c > 0 && d.co <= 0)
-// evaluated on the sign bits with one integer compare (a compound float condition would be
-// materialised lane by lane before the ballot).  The expansion cancels, so the |o|^2 term carries a
-// slack of 1e-5 (|o|^2 + max|c|^2) -- more than 40x the worst rounding error 4 eps (|o|^2 + |c|^2) of
-// either product sum at any scene scale -- which only ever lets MORE pairs through.  This is the
-// build's own test (not reference arithmetic), so FMA is fine; -0/NaN inputs pass (a superset is safe).
+//   pass <=> origin inside the bound, or the ray reaches it ahead of the origin
+//        <=> max(d.co, 0)^2 - s (|co|^2 - R^2) >= 0
+// -- a single float compare, so the ballot reads the compare mask directly (a compound condition
+// would be materialised lane by lane first).  The expansion cancels, so the |o|^2 term carries a slack
+// of 1e-5 (|o|^2 + max|c|^2) -- more than 40x the worst rounding error 4 eps (|o|^2 + |c|^2) of either
+// product sum at any scene scale -- which only ever lets MORE pairs through.  This is the build's own
+// test (not reference arithmetic), so FMA is fine.  A lane without a path gets q = +inf and fails.
 struct RlCullRay {
     RlF3 d;       // direction
     float p;      // -d.o
     RlF3 m;       // -2 s o
     float s, q;   // s, s (|o|^2 - slack)
-    uint32_t idle_bit;
 };
-__device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, uint32_t idle_bit) {
+__device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, bool idle) {
     RlCullRay r;
     r.d = dir;
     r.p = -(dir.x * o.x + dir.y * o.y + dir.z * o.z);
     r.s = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f;
     const float o2 = o.x * o.x + o.y * o.y + o.z * o.z;
     r.m = rl_f3(-2.0f * r.s * o.x, -2.0f * r.s * o.y, -2.0f * r.s * o.z);
-    r.q = r.s * (o2 - 1.0e-5f * (o2 + cmax2));
-    r.idle_bit = idle_bit;
+    r.q = idle ? __builtin_inff() : r.s * (o2 - 1.0e-5f * (o2 + cmax2));
     return r;
 }
 __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, __builtin_fmaf(r.s, b.w, r.q))));
-    const float u = __builtin_fmaf(dd, dd, -cs);
-    return (int)(rl_f2u(u) | ((0u - rl_f2u(cs)) & (rl_f2u(dd) - 1u)) | r.idle_bit) >= 0;
+    const float ahead = __builtin_fmaxf(dd, 0.0f);
+    return __builtin_fmaf(ahead, ahead, -cs) >= 0.0f;
 }
 
 // Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
@@ -249,7 +248,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();
     };
 
-    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit);
+    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
     // ---- sphere clusters: bound cull per ray -> ring A ----
     if (sv.n_clusters != 0) { // even count (rl_scene.cpp pads), two clusters per iteration
         RlF4 b0 = cull[0], b1 = cull[1];
