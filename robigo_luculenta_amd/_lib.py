@@ -104,9 +104,16 @@ SIGNATURES = {
 }
 
 if not os.path.exists(LIB_PATH):
-    raise ImportError(
-        "robigo_luculenta_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-        "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+    # A source checkout without the built library: compile it (hipcc cross-compiles gfx950 without a GPU).
+    # This is still the HIP library -- there is no CPU implementation to fall back to -- and a failed
+    # build is a hard error.
+    import subprocess
+    try:
+        subprocess.run(["make", "-C", os.path.join(HERE, "csrc")], check=True, capture_output=True)
+    except (OSError, subprocess.CalledProcessError) as e:
+        raise ImportError(
+            "robigo_luculenta_amd: %s is missing and could not be built with hipcc --offload-arch=gfx950 (%s); "
+            "run `python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % (LIB_PATH, e))
 
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():

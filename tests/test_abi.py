@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = pytest.importorskip("robigo_luculenta_amd")
+import robigo_luculenta_amd as R  # a missing HIP library is a failure, never a skip
 from robigo_luculenta_amd import _lib  # noqa: E402
 
 

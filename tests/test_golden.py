@@ -47,7 +47,7 @@ def test_image_fixture_oracle():
 
 @pytest.mark.gpu
 def test_gpu_against_fixtures_only():
-    R = pytest.importorskip("robigo_luculenta_amd")
+    import robigo_luculenta_amd as R  # a missing HIP library is a failure, never a skip
     g = np.load(os.path.join(G, "demo_photons.npz"))
     scene = R.Scene.builtin(R.SCENE_DEMO)
     t = R.TraceUnit(0, 1280, 720, n_photons=g["photons"].shape[1])
