@@ -282,3 +282,55 @@ def test_cpp_client_of_the_c_abi_renders_a_png(tmp_path):
     idat = blob[blob.index(b"IDAT") + 4: blob.index(b"IEND") - 8]
     rows = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(72, 1 + 3 * 128)
     assert rows[:, 1:].mean() > 5   # an image, not a black frame
+
+
+def test_full_size_properties_1080p(demo):
+    """BASELINE full size (1920x1080, built-in scene) through size-independent properties, since the oracle
+    cannot trace tens of millions of paths in a test: path/segment counters, additivity over path ranges,
+    fused == un-fused + plot, energy conservation of the splat, clear/gather identities."""
+    objs, cam, scene, oscene = demo
+    W, H = 1920, 1080
+    n = 32 * R.NUMBER_OF_PHOTONS                     # 16.8 M paths
+    t = R.TraceUnit(0, W, H, n_photons=1 << 22)
+    whole, a, b = R.PlotUnit(0, W, H), R.PlotUnit(1, W, H), R.PlotUnit(2, W, H)
+    t.render_fused(scene, whole, n, seed=1, stream=0, first_path_index=0)
+    p0, s0, _ = t.stats()
+    assert p0 == n
+    # additivity: the same paths in two launches give the same counters and the same image up to float order
+    t.render_fused(scene, a, n // 2, seed=1, stream=0, first_path_index=0)
+    t.render_fused(scene, b, n - n // 2, seed=1, stream=0, first_path_index=n // 2)
+    p1, s1, _ = t.stats()
+    assert p1 - p0 == n and s1 - s0 == s0
+    xw, xa, xb = whole.tristimulus_buffer, a.tristimulus_buffer, b.tristimulus_buffer
+    scale = np.abs(xw).max()
+    assert np.allclose(xa + xb, xw, rtol=1e-4, atol=2e-6 * scale)
+    assert abs(float(xw.sum(dtype=np.float64)) / float((xa.astype(np.float64) + xb).sum()) - 1) < 1e-6
+    # a different stream is a different sample of the same image: equal in the mean, not in the pixels
+    t.render_fused(scene, a, n // 2, seed=1, stream=7, first_path_index=0)  # a now holds first half + stream 7
+    xa2 = a.tristimulus_buffer - xa
+    assert not np.array_equal(xa2, xa) and abs(xa2[:, 1].sum(dtype=np.float64) / xa[:, 1].sum(dtype=np.float64) - 1) < 0.01
+    # fused == un-fused + plot, and the splat conserves energy: sum(Y) == sum(prob * ybar(lambda))
+    t.render(scene, seed=1, stream=0, first_path_index=0)
+    ph = t.mapped_photons
+    b.clear()
+    b.plot([t])
+    whole.clear()
+    t.render_fused(scene, whole, t.n_photons, seed=1, stream=0, first_path_index=0)
+    xu, xf = b.tristimulus_buffer, whole.tristimulus_buffer
+    assert np.allclose(xu, xf, rtol=1e-4, atol=2e-6 * np.abs(xu).max())
+    import json
+    tab = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cie1931_xyz.json")))
+    Y = np.array(tab["Y"], dtype=np.float64)
+    idxf = (ph["wavelength"].astype(np.float64) - 380.0) / 5.0
+    i0 = np.clip(np.floor(idxf).astype(int), 0, 79)
+    ybar = Y[i0] * (1 - (idxf - i0)) + Y[i0 + 1] * (idxf - i0)          # cie1931.rs:41-47
+    want_y = float((ph["probability"].astype(np.float64) * ybar).sum())
+    got_y = float(xu[:, 1].sum(dtype=np.float64))
+    assert abs(got_y / want_y - 1) < 1e-5       # bilinear weights sum to one (plot_unit.rs:74-77)
+    # gather of a cleared buffer is the identity; gather clears its input
+    g = R.GatherUnit(W, H)
+    g.accumulate(whole)
+    before = g.tristimulus_buffer
+    assert not whole.tristimulus_buffer.any()
+    g.accumulate(whole)
+    assert g.tristimulus_buffer.tobytes() == before.tobytes()
