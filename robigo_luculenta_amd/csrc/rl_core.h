@@ -236,7 +236,8 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     // A candidate of half-space k survives a filter against the set `mask` when its position lies
     // inside every half-space of the set (Compound::intersect's lies_inside filters, geometry.rs:383-384).
     auto filt = [&](RlCand c, uint32_t mask) -> RlCand {
-        if (!(c.t < NONE)) return c;
+        // No early-out for None: with t = +inf the position is inf/NaN and whatever the tests say, the
+        // candidate stays +inf -- on a 64-wide wave a branch would run both sides anyway.
         const RlF3 pos = rl_add(o, rl_mul(dir, c.t));
         bool in = true;
 #if defined(__HIPCC__)
