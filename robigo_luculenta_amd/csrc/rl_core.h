@@ -165,10 +165,9 @@ RL_HD float rl_plane_t(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* dn_out) {
     const RlF3 lo = rl_sub(o, off);
     const float dn = rl_dot(n, dir);
     *dn_out = dn;
-    if (dn == 0.0f) return -1.0f;
+    // Branch-free: for dn == 0 the quotient is inf/NaN and is discarded; `t > 0` is false for NaN.
     const float t = -rl_dot(n, lo) / dn;
-    if (t <= 0.0f) return -1.0f;
-    return t;
+    return (dn != 0.0f && t > 0.0f) ? t : -1.0f;
 }
 // geometry.rs:123-127
 RL_HD bool rl_inside(RlF3 n, RlF3 off, RlF3 p) { return rl_dot(rl_sub(p, off), n) < 0.0f; }
