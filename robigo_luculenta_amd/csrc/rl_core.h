@@ -42,8 +42,8 @@ RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                           
 }
 RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
     const float m = sqrtf(rl_dot(v, v));
-    if (m == 0.0f) return v;
-    return rl_f3(v.x / m, v.y / m, v.z / m);
+    const RlF3 u = rl_f3(v.x / m, v.y / m, v.z / m); // inf/NaN for m == 0, discarded below
+    return (m == 0.0f) ? v : u;
 }
 RL_HD RlF3 rl_reflect(RlF3 v, RlF3 n) { return rl_sub(v, rl_mul(rl_mul(n, 2.0f), rl_dot(n, v))); }   // vector3.rs:91-93
 RL_HD RlF3 rl_rotate_towards(RlF3 v, RlF3 n) {                                                       // vector3.rs:69-83
