@@ -406,22 +406,32 @@ RL_HD float rl_clamp999(float x) { // material.rs:288-292
     return x;
 }
 
+// EmissiveMaterial::get_intensity scaled by the path's intensity (trace_unit.rs:99-101, material.rs:101-105)
+// for a path that ended on emitter `obj`.
+RL_HD float rl_emission(const RlSceneView& sv, float intensity, float wavelength, uint32_t obj) {
+    const RlF4 ob = sv.objects[2 * obj + 1];
+    return intensity * ((float)rl_boltzmann((double)wavelength, (double)ob.x) * ob.y);
+}
+
+enum { RL_PATH_CONTINUES = 0, RL_PATH_ENDED = 1, RL_PATH_ENDED_ON_EMITTER = 2 };
+
 // One step of TraceUnit::render_ray's loop body after the scan (trace_unit.rs:92-126).
-// Returns true when the path ended; *value is then its contribution (trace_unit.rs:94,100,131).
-RL_HD bool rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint64_t path_index, RlPath* p,
-                     const RlHit& hit, float* value) {
-    if (hit.obj == RL_HIT_NONE) { // The Void
-        *value = 0.0f;
-        return true;
-    }
+// RL_PATH_ENDED: *value is the path's contribution (0: The Void or roulette, trace_unit.rs:94,131).
+// RL_PATH_ENDED_ON_EMITTER: the path hit emitter *emitter; its contribution is
+// rl_emission(sv, p->intensity, p->wavelength, *emitter), left to the caller so that the kernel can
+// evaluate the f64 Planck term for 64 ended paths at once instead of under divergence.
+RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint64_t path_index, RlPath* p,
+                    const RlHit& hit, float* value, uint32_t* emitter) {
+    *value = 0.0f;
+    if (hit.obj == RL_HIT_NONE) return RL_PATH_ENDED; // The Void
     const RlF4 oa = sv.objects[2 * hit.obj];
     const RlF4 ob = sv.objects[2 * hit.obj + 1];
     const uint32_t kinds = rl_f2u(oa.x);
     const uint32_t surface_kind = kinds & 0xffu;
     const uint32_t material_kind = kinds >> 8;
-    if (material_kind == RL_MATERIAL_BLACK_BODY) { // material.rs:101-105
-        *value = p->intensity * ((float)rl_boltzmann((double)p->wavelength, (double)ob.x) * ob.y);
-        return true;
+    if (material_kind == RL_MATERIAL_BLACK_BODY) {
+        *emitter = hit.obj;
+        return RL_PATH_ENDED_ON_EMITTER;
     }
     const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y),
                                      material_kind == RL_MATERIAL_SOAP_BUBBLE);
@@ -483,11 +493,9 @@ RL_HD bool rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint
     p->origin = rl_add(is.position, rl_mul(new_dir, 0.00001f));        // trace_unit.rs:114
     p->continue_chance = p->continue_chance * 0.96f;                   // trace_unit.rs:117
     p->bounce += 1;
-    if (rl_get_unit(rb.w[2]) * 0.85f > p->continue_chance * (1.0f - rl_expf(p->intensity * -20.0f))) { // :122-125
-        *value = 0.0f;
-        return true;
-    }
-    return false;
+    if (rl_get_unit(rb.w[2]) * 0.85f > p->continue_chance * (1.0f - rl_expf(p->intensity * -20.0f))) // :122-125
+        return RL_PATH_ENDED;
+    return RL_PATH_CONTINUES;
 }
 
 // ---- cie1931.rs:20-48 and plot_unit.rs:56-84 ----------------------------------------------------

@@ -102,6 +102,9 @@ struct RlWaveScratch {
     // the path's offset in the launch (lo, hi; ~0 = no path).  Refilled with all 64 lanes busy.
     float stash[10][64];
     uint32_t stash_off[2][64];
+    // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
+    // until 64 of them can be evaluated and splatted with a full exec mask.
+    float emit[5][128];
 };
 
 // Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
@@ -393,6 +396,33 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     p.ior = 1.0f;
     p.bounce = 0;
     uint32_t segments = 0, paths_done = 0;
+    RlLdsF32* emit = (RlLdsF32*)&ws->emit[0][0];
+    uint32_t e_head = 0, e_tail = 0; // wave-uniform ring indices of the emitter queue
+    bool ended_on_emitter = false;
+    uint32_t emit_obj = 0;
+
+    // Evaluates and splats `count` queued paths, one per lane: EmissiveMaterial::get_intensity
+    // (material.rs:101-105), cie1931::get_tristimulus and PlotUnit::plot_pixel (plot_unit.rs:56-84).
+    auto process_emitted = [&](uint32_t count) {
+        rl_wave_sync();
+        if (lane < count) {
+            const uint32_t slot = (e_head + lane) & 127u;
+            const float sx = emit[0 * 128 + slot], sy = emit[1 * 128 + slot], wavelength = emit[2 * 128 + slot];
+            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, rl_f2u(emit[4 * 128 + slot]));
+            if (plot && value != 0.0f) { // adding +0 is the identity
+                const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
+                const RlSplat sp = rl_splat_weights(job.width, job.height, job.aspect_ratio, sx, sy);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float* px = plot + 3ull * sp.idx[k];
+                    unsafeAtomicAdd(px + 0, cie.x * sp.w[k]);
+                    unsafeAtomicAdd(px + 1, cie.y * sp.w[k]);
+                    unsafeAtomicAdd(px + 2, cie.z * sp.w[k]);
+                }
+            }
+        }
+        rl_wave_sync();
+    };
 
     for (;;) {
         // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
@@ -462,32 +492,48 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
         if (active) {
             segments += 1;
             float value;
-            if (rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value)) {
+            uint32_t emitter = 0;
+            const int status = rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value, &emitter);
+            if (status != RL_PATH_CONTINUES) {
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
                 paths_done += 1;
-                if (photons) {
+                if (photons) { // un-fused: the record is written here, the emitter term evaluated in place
+                    if (status == RL_PATH_ENDED_ON_EMITTER) value = rl_emission(sv, p.intensity, p.wavelength, emitter);
                     RlMappedPhoton ph;
                     ph.x = p.sx;
                     ph.y = p.sy;
                     ph.probability = value;
                     ph.wavelength = p.wavelength;
                     photons[my_offset] = ph;
+                } else {
+                    ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
+                    emit_obj = emitter;
                 }
-                if (plot && value != 0.0f) { // plot_unit.rs:87-95 (adding +0 is the identity)
-                    const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, p.wavelength), value);
-                    const RlSplat s = rl_splat_weights(job.width, job.height, job.aspect_ratio, p.sx, p.sy);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        float* px = plot + 3ull * s.idx[k];
-                        unsafeAtomicAdd(px + 0, cie.x * s.w[k]);
-                        unsafeAtomicAdd(px + 1, cie.y * s.w[k]);
-                        unsafeAtomicAdd(px + 2, cie.z * s.w[k]);
-                    }
+            }
+        }
+        if (!photons) {
+            // ---- fused splat (plot_unit.rs:56-95), deferred: queue the paths that ended on a light ----
+            const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
+            if (m != 0) {
+                if (ended_on_emitter) {
+                    const uint32_t slot = (e_tail + rl_mbcnt(m)) & 127u;
+                    emit[0 * 128 + slot] = p.sx;
+                    emit[1 * 128 + slot] = p.sy;
+                    emit[2 * 128 + slot] = p.wavelength;
+                    emit[3 * 128 + slot] = p.intensity;
+                    emit[4 * 128 + slot] = rl_u2f(emit_obj);
+                    ended_on_emitter = false;
+                }
+                e_tail += (uint32_t)__popcll(m);
+                if (e_tail - e_head >= 64u) {
+                    process_emitted(64u);
+                    e_head += 64u;
                 }
             }
         }
     }
+    if (!photons && e_tail != e_head) process_emitted(e_tail - e_head);
     // One atomic per wave for the counters.
     uint32_t s = segments, d = paths_done;
 #pragma unroll

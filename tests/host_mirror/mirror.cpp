@@ -68,7 +68,10 @@ void mirror_render(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t 
         for (;;) {
             const RlHit hit = rl_scan(sv, p.origin, p.direction);
             segs += 1;
-            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value)) break;
+            uint32_t emitter = 0;
+            const int status = rl_bounce(sv, seed, stream, first + i, &p, hit, &value, &emitter);
+            if (status == RL_PATH_ENDED_ON_EMITTER) value = rl_emission(sv, p.intensity, p.wavelength, emitter);
+            if (status != RL_PATH_CONTINUES) break;
         }
         photons[i].x = p.sx;
         photons[i].y = p.sy;
@@ -115,7 +118,8 @@ extern "C" uint64_t mirror_dump_rays(void* scene, uint32_t w, uint32_t h, uint64
                 count++;
             }
             const RlHit hit = rl_scan(sv, p.origin, p.direction);
-            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value)) break;
+            uint32_t emitter = 0;
+            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value, &emitter) != RL_PATH_CONTINUES) break;
         }
     }
     return count;
