@@ -126,6 +126,11 @@ const char* rl_version(void);
  * returns RL_E_INVALID with *n_objects set to the required count. */
 int rl_scene_builtin_desc(int which, int param, RlObjectDesc* objects, uint32_t cap, uint32_t* n_objects,
                           RlCameraDesc* camera);
+/* Scene descriptions as files (the reference hard-codes its scene, app.rs:166-363).  Little-endian binary:
+ * "RLSC" magic, u32 version = 1, u32 n_objects, RlCameraDesc (40 bytes), n_objects x RlObjectDesc (60 bytes).
+ * Host-only.  rl_scene_desc_load follows rl_scene_builtin_desc's capacity protocol. */
+int rl_scene_desc_save(const char* path, const RlSceneDesc* desc);
+int rl_scene_desc_load(const char* path, RlObjectDesc* objects, uint32_t cap, uint32_t* n_objects, RlCameraDesc* camera);
 /* Flattens the description (hex prisms become 8 half-spaces, paraboloids get their derived
  * fields, black bodies their normalisation factor) and uploads it to `device`.  Replaces
  * App::set_up_scene + Arc::new (app.rs:63). */

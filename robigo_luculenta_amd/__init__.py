@@ -41,6 +41,24 @@ def builtin_scene_desc(which=SCENE_DEMO, param=0):
     return objs, cam
 
 
+def save_scene_desc(path, objects, camera):
+    """Writes a scene description file (RLSC v1, see include/robigo_luculenta.h)."""
+    objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+    desc = RlSceneDesc(len(objects), objects.ctypes.data_as(C.c_void_p), RlCameraDesc.from_buffer_copy(bytes(camera)))
+    check(lib.rl_scene_desc_save(path.encode(), C.byref(desc)))
+
+
+def load_scene_desc(path):
+    n = C.c_uint32(0)
+    cam = RlCameraDesc()
+    rc = lib.rl_scene_desc_load(path.encode(), None, 0, C.byref(n), C.byref(cam))
+    if rc not in (0, -1) or (rc == -1 and n.value == 0):
+        check(rc)
+    objs = np.zeros(n.value, dtype=OBJECT_DTYPE)
+    check(lib.rl_scene_desc_load(path.encode(), objs.ctypes.data_as(C.c_void_p), n.value, C.byref(n), C.byref(cam)))
+    return objs, cam
+
+
 class _Handle:
     _destroy = None
 

@@ -68,6 +68,8 @@ SIGNATURES = {
     "rl_device_count": (_i, []),
     "rl_version": (C.c_char_p, []),
     "rl_scene_builtin_desc": (_i, [_i, _i, _vp, _u32, C.POINTER(_u32), C.POINTER(RlCameraDesc)]),
+    "rl_scene_desc_save": (_i, [C.c_char_p, C.POINTER(RlSceneDesc)]),
+    "rl_scene_desc_load": (_i, [C.c_char_p, _vp, _u32, C.POINTER(_u32), C.POINTER(RlCameraDesc)]),
     "rl_scene_create": (_i, [C.POINTER(RlSceneDesc), _i, _pp]),
     "rl_scene_destroy": (_i, [_vp]),
     "rl_trace_unit_create": (_i, [_i, _u32, _u32, _u32, _u32, _pp]),

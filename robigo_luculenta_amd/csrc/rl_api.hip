@@ -209,6 +209,42 @@ int rl_scene_builtin_desc(int which, int param, RlObjectDesc* objects, uint32_t 
     return RL_OK;
 }
 
+int rl_scene_desc_save(const char* path, const RlSceneDesc* desc) {
+    if (!path || !desc || (!desc->objects && desc->n_objects)) return fail(RL_E_INVALID, "null argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return fail(RL_E_IO, std::string("failed to open file ") + path);
+    const uint32_t header[2] = {1u, desc->n_objects};
+    bool ok = std::fwrite("RLSC", 1, 4, f) == 4 && std::fwrite(header, 4, 2, f) == 2 &&
+              std::fwrite(&desc->camera, sizeof(RlCameraDesc), 1, f) == 1 &&
+              std::fwrite(desc->objects, sizeof(RlObjectDesc), desc->n_objects, f) == desc->n_objects;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RL_OK : fail(RL_E_IO, std::string("failed to write scene file ") + path);
+}
+
+int rl_scene_desc_load(const char* path, RlObjectDesc* objects, uint32_t cap, uint32_t* n_objects, RlCameraDesc* camera) {
+    if (!path) return fail(RL_E_INVALID, "null path");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(RL_E_IO, std::string("failed to open file ") + path);
+    char magic[4];
+    uint32_t header[2] = {0, 0};
+    RlCameraDesc cam;
+    bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "RLSC", 4) == 0 && std::fread(header, 4, 2, f) == 2 &&
+              header[0] == 1u && std::fread(&cam, sizeof cam, 1, f) == 1;
+    if (!ok) {
+        std::fclose(f);
+        return fail(RL_E_IO, std::string("not a version-1 RLSC scene file: ") + path);
+    }
+    if (n_objects) *n_objects = header[1];
+    if (camera) *camera = cam;
+    if (!objects || cap < header[1]) {
+        std::fclose(f);
+        return fail(RL_E_INVALID, "object array too small for the scene file");
+    }
+    ok = std::fread(objects, sizeof(RlObjectDesc), header[1], f) == header[1];
+    std::fclose(f);
+    return ok ? RL_OK : fail(RL_E_IO, std::string("truncated scene file ") + path);
+}
+
 int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     if (!out) return fail(RL_E_INVALID, "null output handle");
     *out = nullptr;

@@ -71,3 +71,17 @@ def test_invalid_arguments_return_codes_not_crashes():
     desc = _lib.RlSceneDesc(1, bad.ctypes.data_as(C.c_void_p), R.builtin_scene_desc()[1])
     assert _lib.lib.rl_scene_create(C.byref(desc), 0, C.byref(h)) == -1
     assert b"surface" in _lib.lib.rl_last_error()
+
+
+def test_scene_description_file_round_trip(tmp_path):
+    objs, cam = R.builtin_scene_desc(R.SCENE_GLASS_STRESS)
+    path = str(tmp_path / "scene.rlsc")
+    R.save_scene_desc(path, objs, cam)
+    assert os.path.getsize(path) == 12 + 40 + 60 * len(objs)
+    objs2, cam2 = R.load_scene_desc(path)
+    assert objs2.tobytes() == objs.tobytes() and bytes(cam2) == bytes(cam)
+    open(path, "r+b").write(b"XXXX")
+    with pytest.raises(R.RlError):
+        R.load_scene_desc(path)
+    with pytest.raises(R.RlError):
+        R.load_scene_desc(str(tmp_path / "missing.rlsc"))
