@@ -252,10 +252,12 @@ def test_scene_too_large_for_lds_spills_to_global_fetch():
     assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
 
 
-@pytest.mark.parametrize("seed", [1, 4, 6])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_random_scenes_bit_exact_on_device(seed):
     from _random_scene import random_scene
-    objs, cam = random_scene(seed, n_spheres=40 + 30 * seed)
+    # from a handful of spheres (direct list only) to several hundred (60+ clusters), 0..20 prisms
+    objs, cam = random_scene(seed, n_spheres=[5, 20, 33, 64, 100, 150, 220, 300, 400, 520, 31, 32][seed - 1],
+                             n_prisms=[0, 1, 3, 6, 10, 20, 2, 4, 8, 12, 0, 5][seed - 1])
     scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
     N = 1 << 15
     for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):

@@ -82,7 +82,7 @@ def test_plot_weights_and_cie_lookup_bit_exact():
     assert M.plot(96, 54, edge).tobytes() == O.plot(96, 54, edge).tobytes()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_random_scenes_bit_exact(seed):
     """Culls must stay conservative on arbitrary geometry: overlapping, nested and huge spheres, randomly
     oriented prisms, glass everywhere (un-normalised directions, material.rs:246)."""
