@@ -269,6 +269,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_prisms = append(fs.prisms);
     lay.off_objects = append(fs.objects);
     lay.off_cull = append(fs.cull_bounds);
+    lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     lay.off_cie = (uint32_t)blob.size();
     const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
@@ -286,8 +287,6 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.n_parabs = (uint32_t)(fs.parabs.size() / 3);
     lay.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
     lay.n_objects = (uint32_t)(fs.objects.size() / 2);
-    lay.camera = fs.camera;
-    lay.screen_distance = fs.screen_distance;
 
     RlScene* s = new (std::nothrow) RlScene();
     if (!s) return fail(RL_E_INVALID, "out of host memory");

@@ -114,7 +114,11 @@ RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t see
     const float t = rl_get_unit(b0.w[3]);
 
     // make_camera(t)
-    const RlCameraDesc& cd = sv.camera;
+    const float* crec = (const float*)sv.camera_rec;
+    RlCameraDesc cd;
+    cd.phi0 = crec[0]; cd.phi1 = crec[1]; cd.alpha0 = crec[2]; cd.alpha1 = crec[3]; cd.dist0 = crec[4]; cd.dist1 = crec[5];
+    cd.fov_over_pi = crec[6]; cd.focal_factor = crec[7]; cd.depth_of_field = crec[8]; cd.chromatic_abberation = crec[9];
+    const float screen_distance = crec[10];
     const float phi = RL_PI_F * (cd.phi0 + cd.phi1 * t);
     const float alpha = RL_PI_F * (cd.alpha0 + cd.alpha1 * t);
     const float distance = cd.dist0 + cd.dist1 * t;
@@ -141,7 +145,7 @@ RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t see
     // Camera::get_screen_ray
     const float xs = x * zoom;
     const float ys = y * zoom;
-    const RlF3 direction = rl_normalise(rl_f3(xs, sv.screen_distance, -ys));
+    const RlF3 direction = rl_normalise(rl_f3(xs, screen_distance, -ys));
     const RlF3 focus_point = rl_mul(direction, focal_distance / direction.y);
     float sin_d, cos_d;
     rl_sincosf(dof_angle, &sin_d, &cos_d);

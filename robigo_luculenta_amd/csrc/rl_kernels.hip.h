@@ -28,11 +28,9 @@
 
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
-    uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cull, off_cie, off_sphere_obj, total_f4;
+    uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cull, off_camera, off_cie, off_sphere_obj, total_f4;
     float cull_cmax2; // RlFlatScene::cull_cmax2
     uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
-    RlCameraDesc camera;
-    float screen_distance;
 };
 
 struct RlTraceJob {
@@ -372,8 +370,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;
     sv.n_objects = lay.n_objects;
-    sv.camera = lay.camera;
-    sv.screen_distance = lay.screen_distance;
+    sv.camera_rec = base + lay.off_camera;
 
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];

@@ -365,6 +365,9 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     fs.camera = desc->camera;
     const float fov = PI * desc->camera.fov_over_pi;
     fs.screen_distance = 1.0f / rl_tanf(fov * 0.5f); // camera.rs:56
+    fs.camera_rec.assign(3, RlF4{0.0f, 0.0f, 0.0f, 0.0f});
+    std::memcpy(fs.camera_rec.data(), &fs.camera, sizeof(RlCameraDesc));
+    reinterpret_cast<float*>(fs.camera_rec.data())[10] = fs.screen_distance;
     for (uint32_t i = 0; i < desc->n_objects; ++i) {
         const RlObjectDesc& o = desc->objects[i];
         const float objbits = rl_u2f(i);

@@ -57,8 +57,10 @@ struct RlSceneView {
     uint32_t n_direct_padded;  // multiple of 4; records [n_direct, n_direct_padded + 4) are dummies
     uint32_t cluster_base;     // first cluster record (= n_direct_padded + 4)
     uint32_t n_clusters;       // even; each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
-    RlCameraDesc camera;
-    float screen_distance; // 1 / tan(field_of_view / 2), camera.rs:56 (constant per scene)
+    // 3 records: the 10 floats of RlCameraDesc, then screen_distance = 1 / tan(field_of_view / 2)
+    // (camera.rs:56, constant per scene).  Read from memory where a path starts instead of being held
+    // in a dozen scalar registers across the whole persistent loop.
+    const RlF4* camera_rec;
 };
 
 // Host-side flattened scene (built once by rl_scene_create).
@@ -72,9 +74,10 @@ struct RlFlatScene {
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView
     RlCameraDesc camera;
     float screen_distance;
+    std::vector<RlF4> camera_rec; // see RlSceneView
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).
     size_t staged_bytes() const {
-        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size()) * sizeof(RlF4) +
+        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size() + camera_rec.size()) * sizeof(RlF4) +
                sphere_obj.size() * sizeof(uint32_t);
     }
 };
