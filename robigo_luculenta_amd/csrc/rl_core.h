@@ -419,6 +419,23 @@ RL_HD float rl_emission(const RlSceneView& sv, float intensity, float wavelength
 
 enum { RL_PATH_CONTINUES = 0, RL_PATH_ENDED = 1, RL_PATH_ENDED_ON_EMITTER = 2 };
 
+// Russian roulette, trace_unit.rs:122-125: `rand * 0.85 > continue_chance * (1 - exp(intensity * -20))`.
+// Only the outcome of the comparison is used.  On the GPU the f64 exp (~50 f64 operations per bounce) is
+// skipped when the hardware exp2 already decides it: e_fast is within 4e-6 of the exactly rounded
+// exp(fl(intensity * -20)) for intensity in [0, 1] (1.8e-6 from the rounded exponent, 1.2e-6 from the
+// product the exact form rounds differently, 1 ulp of v_exp_f32, the roundings of 1 - e and of the
+// product with continue_chance <= 1), so outside a 2e-5 band both forms agree; inside it (or for any
+// other lane of the wave, the branch is wave-uniform) the exact form decides.
+RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float e_fast = __builtin_amdgcn_exp2f(intensity * -28.853901f); // -20 log2(e)
+    const float gap = unit * 0.85f - continue_chance * (1.0f - e_fast);
+    const bool undecided = !(fabsf(gap) >= 2.0e-5f) || !(intensity >= 0.0f && intensity <= 1.0f);
+    if (__builtin_amdgcn_ballot_w64(undecided) == 0) return gap > 0.0f;
+#endif
+    return unit * 0.85f > continue_chance * (1.0f - rl_expf(intensity * -20.0f));
+}
+
 // One step of TraceUnit::render_ray's loop body after the scan (trace_unit.rs:92-126).
 // RL_PATH_ENDED: *value is the path's contribution (0: The Void or roulette, trace_unit.rs:94,131).
 // RL_PATH_ENDED_ON_EMITTER: the path hit emitter *emitter; its contribution is
@@ -497,9 +514,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
     p->origin = rl_add(is.position, rl_mul(new_dir, 0.00001f));        // trace_unit.rs:114
     p->continue_chance = p->continue_chance * 0.96f;                   // trace_unit.rs:117
     p->bounce += 1;
-    if (rl_get_unit(rb.w[2]) * 0.85f > p->continue_chance * (1.0f - rl_expf(p->intensity * -20.0f))) // :122-125
-        return RL_PATH_ENDED;
-    return RL_PATH_CONTINUES;
+    return rl_roulette_ends(rl_get_unit(rb.w[2]), p->continue_chance, p->intensity) ? RL_PATH_ENDED : RL_PATH_CONTINUES;
 }
 
 // ---- cie1931.rs:20-48 and plot_unit.rs:56-84 ----------------------------------------------------
