@@ -252,6 +252,38 @@ def test_scene_too_large_for_lds_spills_to_global_fetch():
     assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
 
 
+def test_degenerate_scenes_and_empty_launches(demo):
+    """Edge cases of the scan: the empty scene (every path ends in The Void, scene.rs:43-60 returns None),
+    scenes that hold a single surface kind (each of the kernel's per-kind loops runs with the others
+    empty), a zero-path fused launch, and zero-sized units."""
+    from _random_scene import random_scene
+    full, cam = random_scene(3, n_spheres=40, n_prisms=3, n_planes=2, n_circles=2, n_parabs=2)
+    N = 1 << 12
+    subsets = {"empty": full[:0]}
+    for kind, name in ((0, "spheres"), (1, "planes"), (2, "circles"), (3, "paraboloids"), (4, "prisms")):
+        subsets[name] = full[full["surface_kind"] == kind].copy()
+    subsets["one emissive sphere"] = full[:1].copy()
+    for name, objs in subsets.items():
+        scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+        for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+            t = R.TraceUnit(0, 160, 90, n_photons=N)
+            t.set_fetch(fetch)
+            t.render(scene, seed=5, stream=2, first_path_index=1000)
+            want, segs = oscene.render(160, 90, 5, 2, 1000, N, threads=4)
+            assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs, name
+        if name == "empty":
+            assert not t.mapped_photons["probability"].any() and segs == N
+    objs, cam, scene, oscene = demo
+    t = R.TraceUnit(0, 64, 36, n_photons=64)
+    plot = R.PlotUnit(0, 64, 36)
+    t.render_fused(scene, plot, 0, seed=1, stream=0, first_path_index=0)   # nothing to do, nothing written
+    assert t.stats()[0] == 0 and not plot.tristimulus_buffer.any()
+    for bad in (dict(width=0, height=36, n_photons=64), dict(width=64, height=0, n_photons=64),
+                dict(width=64, height=36, n_photons=0)):
+        with pytest.raises(R.RlError):
+            R.TraceUnit(0, bad["width"], bad["height"], n_photons=bad["n_photons"])
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
 def test_random_scenes_bit_exact_on_device(seed):
     from _random_scene import random_scene

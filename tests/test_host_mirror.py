@@ -93,3 +93,17 @@ def test_random_scenes_bit_exact(seed):
     got, segs2 = sm.render(320, 180, seed, 0, 0, 40000)
     assert segs == segs2 and got.tobytes() == want.tobytes()
     assert (want["probability"] > 0).any()
+
+
+def test_degenerate_scenes_bit_exact():
+    """The empty scene (scene.rs:43-60 returns None for every ray) and scenes of a single surface kind."""
+    from _random_scene import random_scene
+    full, cam = random_scene(3, n_spheres=40, n_prisms=3, n_planes=2, n_circles=2, n_parabs=2)
+    subsets = [full[:0], full[:1].copy()] + [full[full["surface_kind"] == k].copy() for k in range(5)]
+    for objs in subsets:
+        want, segs = O.Scene(objs, cam).render(160, 90, 5, 2, 1000, 1 << 11, threads=4)
+        got = M.Scene(objs, cam).render(160, 90, 5, 2, 1000, 1 << 11)
+        got = got[0] if isinstance(got, tuple) else got
+        assert got.tobytes() == want.tobytes()
+        if len(objs) == 0:
+            assert segs == 1 << 11 and not want["probability"].any()
