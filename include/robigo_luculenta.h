@@ -279,7 +279,8 @@ int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
 /* Not a reference interface: evaluates the shared numerics header (csrc/rl_math.h) on the GPU so a
  * test can check that the hipcc and g++ builds agree bit-for-bit.  fn: 0 sin, 1 cos, 2 tan, 3 exp,
  * 4 ln, 5 acos, 6 SF10 index of refraction (material.rs:203-213), 7 sqrt, 8 x[i] / x[i+1 mod n],
- * 9 x^(1/2.4) (srgb.rs:24). */
+ * 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette decision (trace_unit.rs:122-125) for the triples
+ * (x[i], x[m+i], x[2m+i]) = (rand, continue_chance, intensity), i < m = n / 3, result 1 or 0 in y[i]. */
 int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
 
 #ifdef __cplusplus

@@ -39,6 +39,32 @@ def test_math_header_bit_exact_on_device(fn, lo, hi):
     assert got.tobytes() == want.tobytes()
 
 
+def test_roulette_fast_path_decides_like_the_exact_form():
+    """trace_unit.rs:122-125.  The kernel decides `rand * 0.85 > continue_chance * (1 - exp(-20 intensity))`
+    from the hardware exp2 when the two sides are more than 2e-5 apart (rl_roulette_ends) and from the exact
+    f64 exp otherwise; the decision must always be the exact form's.  Whole waves of 64 share one distance
+    from the threshold, so waves just outside the band take the fast path; out-of-range intensities
+    (> 1, negative, NaN, inf) must fall back to the exact form."""
+    rng = np.random.default_rng(11)
+    m = 1 << 18
+    intensity = rng.uniform(0, 1, m).astype(np.float32) ** 2
+    intensity[::7] = rng.uniform(0.0, 0.05, len(intensity[::7])).astype(np.float32)   # where 1 - e is small
+    cc = (0.96 ** rng.integers(1, 40, m)).astype(np.float32)
+    e = O.math_f32("exp", intensity * np.float32(-20.0))
+    threshold = cc * (np.float32(1.0) - e)
+    deltas = np.array([0, 1e-7, 1e-6, 5e-6, 1.5e-5, 1.9e-5, 2.1e-5, 2.5e-5, 3e-5, 1e-4, 1e-3, 1e-1], np.float32)
+    delta = np.repeat(deltas[rng.integers(0, len(deltas), m // 64)], 64) * rng.choice([-1, 1], m).astype(np.float32)
+    unit = np.clip((threshold + delta) / np.float32(0.85), 0, 1).astype(np.float32)
+    odd = rng.integers(0, m, 512)                       # out-of-range intensities in some waves
+    intensity[odd] = np.resize(np.array([1.5, -0.25, np.nan, np.inf, -np.inf, 1.0000001], np.float32), len(odd))
+    e = O.math_f32("exp", intensity * np.float32(-20.0))
+    with np.errstate(invalid="ignore", over="ignore"):
+        want = (unit * np.float32(0.85) > cc * (np.float32(1.0) - e)).astype(np.float32)
+    got = R.math_probe("roulette", np.concatenate([unit, cc, intensity]))[:m]
+    assert np.array_equal(got, want)
+    assert 0.2 < want.mean() < 0.8                     # both outcomes occur
+
+
 def test_ieee_sqrt_div_and_f64_islands_on_device():
     rng = np.random.default_rng(8)
     x = np.exp(rng.uniform(-30, 30, 1 << 16)).astype(np.float32)
