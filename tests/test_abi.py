@@ -27,6 +27,13 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_rust_binding_declares_every_entry_point():
+    """bindings/rust/ffi.rs (what a maintainer adds as src/ffi.rs) must not drift from the header."""
+    rust = open(os.path.join(ROOT, "bindings", "rust", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (rl_[a-z0-9_]+)\s*\(", rust))
+    assert declared == set(declared_symbols())
+
+
 def test_pod_layouts_are_frozen():
     assert C.sizeof(_lib.RlVector3) == 12         # gather_unit.rs:75 transmutes to [u8; 12]
     assert C.sizeof(_lib.RlMappedPhoton) == 16    # trace_unit.rs:23-37
