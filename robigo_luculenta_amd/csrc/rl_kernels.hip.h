@@ -15,7 +15,9 @@
 //     evaluated 64 (item, ray) pairs at a time, results min-merged per ray with ds_min_u64;
 //   * results leave either as MappedPhoton records (un-fused, bit-comparable with the CPU) or as
 //     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
-//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (~90 % busy).
+//     in fused mode the paths that ended on a light wait in a per-wave LDS queue until 64 of them can
+//     be evaluated (f64 Planck term) and splatted with a full exec mask;
+//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (~95 % busy).
 #pragma once
 #include <hip/hip_runtime.h>
 
