@@ -269,9 +269,10 @@ typedef struct RlAppStats {
 } RlAppStats;
 
 /* App::new + the worker loops (app.rs:54-111) until max_batches trace tasks are done, gathered and
- * tonemapped once more.  Trace task number k (in scheduler order) renders paths
- * [k * photons_per_batch, (k + 1) * photons_per_batch), so the final image does not depend on which
- * worker or unit ran which task.  rgb_out (may be NULL) receives the last RGB8 image. */
+ * tonemapped once more.  The batches cover the path indices [0, max_batches * photons_per_batch) exactly
+ * once (un-fused: trace task number k, in scheduler order, renders batch k; fused: each plot task renders the
+ * batches of its trace units as one launch over the next contiguous range), so the final image does not
+ * depend on which worker or unit ran which task.  rgb_out (may be NULL) receives the last RGB8 image. */
 int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */

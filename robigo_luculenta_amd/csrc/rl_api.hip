@@ -64,6 +64,9 @@ struct RlTraceUnit {
     std::vector<EventPair> pending, pool;
     double kernel_ms;
     uint64_t launches;
+    size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
+    bool tuned_stage;  // kernel variant,
+    int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
 };
 
 struct RlPlotUnit {
@@ -122,12 +125,16 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     auto kernel = stage ? rl_trace_kernel<true> : rl_trace_kernel<false>;
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
-    if (dyn > 64 * 1024)
-        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-    int per_cu = 1;
-    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
-    if (per_cu < 1) per_cu = 1;
-    uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)per_cu;
+    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage) { // once per (unit, scene size)
+        // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
+        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int per_cu = 1;
+        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
+        u->tuned_per_cu = per_cu < 1 ? 1 : per_cu;
+        u->tuned_dyn = dyn;
+        u->tuned_stage = stage;
+    }
+    uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
 
@@ -335,6 +342,9 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->fetch = RL_FETCH_LDS;
     u->kernel_ms = 0.0;
     u->launches = 0;
+    u->tuned_dyn = 0;
+    u->tuned_stage = false;
+    u->tuned_per_cu = 0;
     u->cu_count = 256;
     hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));
     if (e == hipSuccess) e = hipMemset(u->photons, 0, (size_t)n_photons * sizeof(RlMappedPhoton)); // MappedPhoton::new

@@ -30,6 +30,7 @@ struct AppState {
     std::mutex lock;                       // Arc<Mutex<TaskScheduler>>, app.rs:57
     std::chrono::steady_clock::time_point t0;
     uint64_t traces_issued = 0;            // under `lock`
+    std::atomic<uint64_t> fused_next_path{0}; // fused mode: next unrendered path index
     std::vector<uint64_t> trace_first_path; // per trace unit: the path range of its current task
     std::vector<int> trace_target_plot;    // fused mode: plot unit that received the unit's photons (-1 none)
     uint64_t tasks[5] = {0, 0, 0, 0, 0};
@@ -151,11 +152,18 @@ void execute_task(AppState& a, const RlTask& task) {
             for (uint32_t i = 0; i < task.n_units; ++i) units.push_back(a.trace_units[task.units[i]]);
             rc = rl_plot_unit_plot(a.plot_units[task.unit], units.data(), (uint32_t)units.size());
         } else {
-            // every unit renders on its own stream: launch them all, then wait for all
-            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i)
-                rc = rl_trace_unit_render_fused(a.trace_units[task.units[i]], a.scene, a.plot_units[task.unit], c.seed, c.stream,
-                                                a.trace_first_path[task.units[i]], a.photons);
-            for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) rc = rl_trace_unit_sync(a.trace_units[task.units[i]]);
+            // The batches of all the trace units of this task go out as ONE launch over one contiguous
+            // range of path indices: a 524,288-path launch of its own would keep an MI355X busy for 0.15 ms
+            // and spend twice that waiting for its longest paths, n of them together amortise that tail.
+            // Ranges are handed out in execution order, so every index below traces_issued * photons is
+            // rendered exactly once whichever worker plots which units.
+            if (task.n_units != 0) {
+                const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
+                const uint64_t first = a.fused_next_path.fetch_add(n);
+                RlTraceUnit* u = a.trace_units[task.units[0]];
+                rc = rl_trace_unit_render_fused(u, a.scene, a.plot_units[task.unit], c.seed, c.stream, first, n);
+                if (rc == RL_OK) rc = rl_trace_unit_sync(u);
+            }
         }
         break;
     case RL_TASK_GATHER: // app.rs:143-152 (save moved to tonemap time)
