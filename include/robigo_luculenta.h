@@ -257,6 +257,9 @@ typedef struct RlAppConfig {
     const char* checkpoint;      /* GatherUnit::save target, written at every tonemap and at the end; NULL = none */
     int resume;                  /* non-zero: rl_gather_unit_load(checkpoint) before rendering (gather_unit.rs:42-43) */
     int verbose;                 /* print the reference's progress lines (task_scheduler.rs:242-325) */
+    uint32_t sleep_us;           /* how long Task::Sleep waits before the worker asks again.  The reference sleeps
+                                    100 ms (app.rs:129) because its tasks take seconds; a task here takes about a
+                                    millisecond, so 0 selects 200 us.  100000 restores the reference's value. */
 } RlAppConfig;
 
 typedef struct RlAppStats {

@@ -274,12 +274,12 @@ class TaskScheduler(_Handle):
 
 def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_batch=NUMBER_OF_PHOTONS, seed=1, stream=0,
             scene=SCENE_DEMO, scene_param=0, tonemap_interval_ms=30000, fused=False, output_ppm=None, checkpoint=None,
-            resume=False, verbose=False):
+            resume=False, verbose=False, sleep_us=0):
     """App::new + worker loops (app.rs:54-111) on one GPU until `max_batches` trace tasks are done.
     Returns (rgb image as (H, W, 3) uint8, stats dict)."""
     cfg = RlAppConfig(width, height, device, concurrency, photons_per_batch, seed, stream, scene, scene_param, max_batches,
                       tonemap_interval_ms, int(fused), output_ppm.encode() if output_ppm else None,
-                      checkpoint.encode() if checkpoint else None, int(resume), int(verbose))
+                      checkpoint.encode() if checkpoint else None, int(resume), int(verbose), sleep_us)
     stats = RlAppStats()
     rgb = np.zeros((height, width, 3), dtype=np.uint8)
     check(lib.rl_app_run(C.byref(cfg), C.byref(stats), rgb.ctypes.data_as(C.c_void_p)))

@@ -50,7 +50,7 @@ class RlAppConfig(C.Structure):
                 ("photons_per_batch", C.c_uint32), ("seed", C.c_uint64), ("stream", C.c_uint32),
                 ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
                 ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
-                ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int)]
+                ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32)]
 
 
 class RlAppStats(C.Structure):

@@ -1,8 +1,11 @@
 // rl_api.hip -- implementation of include/robigo_luculenta.h over the gfx950 kernels.
 //
-// Ordering model: every trace unit owns a blocking HIP stream; plot / gather / tonemap work and all
-// copies run on the device's null stream, which HIP orders against blocking streams, so a fused
-// render followed by a gather needs no explicit event.  Entry points never throw.
+// Ordering model: every trace unit and every plot unit owns a blocking HIP stream; gather / tonemap
+// work, clears and all copies run on the device's null stream, which HIP orders against blocking
+// streams, so a (fused) render or a plot followed by a gather needs no explicit event.  The one
+// hazard between two blocking streams -- PlotUnit::plot reading mapped_photons that the trace unit's
+// next render overwrites -- is closed with an event the trace unit's stream waits on.  Trace and plot
+// work of different units therefore overlap on the device.  Entry points never throw.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -75,6 +78,8 @@ struct RlPlotUnit {
     float* xyz;
     bool owns;
     RlF4* cie;
+    hipStream_t stream; // rl_plot_kernel launches
+    hipEvent_t plotted; // recorded after the last plot kernel of a PlotUnit::plot call
 };
 
 struct RlGatherUnit {
@@ -456,6 +461,8 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     u->xyz = external_xyz;
     u->owns = external_xyz == nullptr;
     u->cie = nullptr;
+    u->stream = nullptr;
+    u->plotted = nullptr;
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     hipError_t e = hipSuccess;
     if (u->owns) {
@@ -464,6 +471,8 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     }
     if (e == hipSuccess) e = hipMalloc((void**)&u->cie, sizeof RL_CIE1931_XYZ0);
     if (e == hipSuccess) e = hipMemcpy(u->cie, RL_CIE1931_XYZ0, sizeof RL_CIE1931_XYZ0, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreate(&u->stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->plotted, hipEventDisableTiming);
     if (e != hipSuccess) {
         rl_plot_unit_destroy(u);
         return fail(RL_E_HIP, std::string("plot unit allocation: ") + hipGetErrorString(e));
@@ -475,6 +484,11 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
 int rl_plot_unit_destroy(RlPlotUnit* u) {
     if (!u) return RL_OK;
     (void)hipSetDevice(u->device);
+    if (u->stream) {
+        (void)hipStreamSynchronize(u->stream);
+        (void)hipStreamDestroy(u->stream);
+    }
+    if (u->plotted) (void)hipEventDestroy(u->plotted);
     if (u->owns && u->xyz) (void)hipFree(u->xyz);
     if (u->cie) (void)hipFree(u->cie);
     delete u;
@@ -491,9 +505,15 @@ int rl_plot_unit_plot(RlPlotUnit* u, RlTraceUnit* const* trace_units, uint32_t n
     for (uint32_t k = 0; k < n_trace_units; ++k) {           // app.rs:138-140
         RlTraceUnit* t = trace_units[k];
         if (!t || t->device != u->device) return fail(RL_E_STATE, "trace unit missing or on another device");
-        hipLaunchKernelGGL(rl_plot_kernel, dim3(grid_for(t->n_photons, cus)), dim3(RL_BLOCK), 0, 0, t->photons, t->n_photons,
-                           u->cie, u->width, u->height, aspect, u->xyz);
+        hipLaunchKernelGGL(rl_plot_kernel, dim3(grid_for(t->n_photons, cus)), dim3(RL_BLOCK), 0, u->stream, t->photons,
+                           t->n_photons, u->cie, u->width, u->height, aspect, u->xyz);
         RL_HIP(hipGetLastError());
+    }
+    // The trace units may be handed out again as soon as this returns (task_scheduler.rs:262-271): their
+    // next render must not overwrite mapped_photons before the kernels above have read them.
+    if (n_trace_units != 0) {
+        RL_HIP(hipEventRecord(u->plotted, u->stream));
+        for (uint32_t k = 0; k < n_trace_units; ++k) RL_HIP(hipStreamWaitEvent(trace_units[k]->stream, u->plotted, 0));
     }
     return RL_OK;
 }

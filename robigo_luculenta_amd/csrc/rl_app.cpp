@@ -2,9 +2,11 @@
 // executes them, with the GPU units of the C ABI where the reference has CPU loops.
 //
 // Same structure as the reference: `concurrency` OS threads, one Mutex around the scheduler
-// (app.rs:57,107), tasks executed outside the lock, Sleep = 100 ms (app.rs:129).  Differences, all
-// forced by "the reference never terminates and is unseedable": a batch budget (max_batches), a path
-// range per trace task, and explicit checkpoint / image file names.
+// (app.rs:57,107), tasks executed outside the lock.  Differences, forced by "the reference never
+// terminates and is unseedable": a batch budget (max_batches), a path range per trace task, explicit
+// checkpoint / image file names; and forced by the time scale (a task takes a millisecond, not
+// seconds): Task::Sleep waits 200 us instead of 100 ms (app.rs:129; RlAppConfig::sleep_us), and in
+// fused mode a Plot task renders the batches of its trace units as one launch.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -139,8 +141,8 @@ void execute_task(AppState& a, const RlTask& task) {
     const RlAppConfig& c = *a.cfg;
     int rc = RL_OK;
     switch (task.kind) {
-    case RL_TASK_SLEEP: // app.rs:128-130
-        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    case RL_TASK_SLEEP: // app.rs:128-130, at the time scale of GPU tasks (RlAppConfig::sleep_us)
+        std::this_thread::sleep_for(std::chrono::microseconds(c.sleep_us ? c.sleep_us : 200u));
         break;
     case RL_TASK_TRACE: // app.rs:132-134
         if (!c.fused) rc = rl_trace_unit_render(a.trace_units[task.unit], a.scene, c.seed, c.stream, a.trace_first_path[task.unit]);
