@@ -83,7 +83,11 @@ def cpu_baseline(objs, cam, width, height, seconds_target=15.0):
     dt0 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, 0, n0, None, C.byref(segs), threads)
     n = int(max(n0, min(n0 * seconds_target / max(dt0, 1e-3), 64 * BATCH)))
     dt = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0, n, None, C.byref(segs), threads)
+    segs1 = C.c_uint64(0)                     # the 1-thread number beside it (~3 s)
+    n1 = max(20000, int(n / threads * 3.0 / max(dt, 1e-3)))
+    dt1 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0 + n, n1, None, C.byref(segs1), 1)
     return {"value": segs.value / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "one_thread": {"value": segs1.value / dt1 / 1e6, "unit": "Mrays/s", "sample": "%d paths, %.1f s" % (n1, dt1)},
             "sample": "%d camera paths (%d rays) of the same scene/resolution, seed 1, %d threads, %.1f s"
                       % (n, segs.value, threads, dt),
             "mpaths_per_s": n / dt / 1e6, "batches_per_s": n / dt / BATCH}
@@ -227,6 +231,7 @@ def main():
             "segments_per_path": total_rays / max(total_paths, 1.0),
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
                          "traffic": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step,
                          "traffic_note": "bytes per launch, scaled from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/ "
                                          "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
