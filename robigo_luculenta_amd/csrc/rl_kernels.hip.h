@@ -26,7 +26,7 @@
 
 #define RL_BLOCK 256        // streaming kernels (plot, gather, tonemap)
 #define RL_TRACE_BLOCK 1024 // trace kernel: one workgroup of 16 waves per CU shares one LDS copy of the scene
-#define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills)
+#define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills) in large launches
 
 struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
@@ -433,12 +433,17 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 if (drained) break;
                 // Refill: all 64 lanes generate one camera ray each (full exec mask) into the stash.
                 if (chunk_next == chunk_end) {
+                    // Small launches (fewer than 16 paths per lane of the grid: the reference's 524,288-path
+                    // batch is 2 per lane) take one stash refill at a time, so that every wave gets work;
+                    // with RL_CHUNK the first half of the waves would take everything.
+                    const unsigned long long chunk =
+                        job.n_paths >= (unsigned long long)gridDim.x * (RL_TRACE_BLOCK * 16ull) ? RL_CHUNK : 64ull;
                     unsigned long long b = 0;
-                    if (lane == 0) b = atomicAdd(&queue[0], RL_CHUNK);
+                    if (lane == 0) b = atomicAdd(&queue[0], chunk);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
                     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
                     chunk_next = ((uint64_t)hi << 32) | lo;
-                    chunk_end = chunk_next + RL_CHUNK;
+                    chunk_end = chunk_next + chunk;
                 }
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
