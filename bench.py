@@ -233,6 +233,9 @@ def main():
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                          "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
                          "traffic": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step,
+                         "hbm": {"achieved": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step / (launch_ms * 1e-3) / 1e9,
+                                 "peak": 8000.0, "unit": "GB/s",
+                                 "frac": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step / (launch_ms * 1e-3) / 8e12},
                          "traffic_note": "bytes per launch, scaled from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/ "
                                          "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms,
