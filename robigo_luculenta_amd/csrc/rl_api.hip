@@ -68,7 +68,7 @@ struct RlTraceUnit {
     double kernel_ms;
     uint64_t launches;
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
-    bool tuned_stage;  // kernel variant,
+    bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
 };
 
@@ -128,9 +128,11 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
     const size_t blob_bytes = scene->staged_bytes;
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
-    auto kernel = stage ? rl_trace_kernel<true> : rl_trace_kernel<false>;
+    const bool fused = plot != nullptr;
+    auto kernel = stage ? (fused ? rl_trace_kernel<true, true> : rl_trace_kernel<true, false>)
+                        : (fused ? rl_trace_kernel<false, true> : rl_trace_kernel<false, false>);
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
-    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage) { // once per (unit, scene size)
+    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused) { // once per (unit, scene size)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int per_cu = 1;
@@ -138,6 +140,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         u->tuned_per_cu = per_cu < 1 ? 1 : per_cu;
         u->tuned_dyn = dyn;
         u->tuned_stage = stage;
+        u->tuned_fused = fused;
     }
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
@@ -349,6 +352,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->launches = 0;
     u->tuned_dyn = 0;
     u->tuned_stage = false;
+    u->tuned_fused = false;
     u->tuned_per_cu = 0;
     u->cu_count = 256;
     hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));

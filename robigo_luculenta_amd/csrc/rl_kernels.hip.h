@@ -342,7 +342,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // queue[0] = next unassigned path offset of this launch (zeroed before each launch),
 // queue[1] = cumulative segments, queue[2] = cumulative paths.
 // Dynamic LDS: [scene blob when STAGE_LDS][RlWaveScratch x 16].
-template <bool STAGE_LDS>
+// FUSED: paths that end on a light are splatted into `plot` (photons unused); otherwise every path's
+// MappedPhoton goes to `photons` (plot unused).  A compile-time switch so neither variant carries the
+// other's code and registers.
+template <bool STAGE_LDS, bool FUSED>
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                                   RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                                   float* __restrict__ plot,
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             const uint32_t slot = (e_head + lane) & 127u;
             const float sx = emit[0 * 128 + slot], sy = emit[1 * 128 + slot], wavelength = emit[2 * 128 + slot];
             const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, rl_f2u(emit[4 * 128 + slot]));
-            if (plot && value != 0.0f) { // adding +0 is the identity
+            if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
                 const RlSplat sp = rl_splat_weights(job.width, job.height, job.aspect_ratio, sx, sy);
 #pragma unroll
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
                 paths_done += 1;
-                if (photons) { // un-fused: the record is written here, the emitter term evaluated in place
+                if (!FUSED) { // the record is written here, the emitter term evaluated in place
                     if (status == RL_PATH_ENDED_ON_EMITTER) value = rl_emission(sv, p.intensity, p.wavelength, emitter);
                     RlMappedPhoton ph;
                     ph.x = p.sx;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 }
             }
         }
-        if (!photons) {
+        if (FUSED) {
             // ---- fused splat (plot_unit.rs:56-95), deferred: queue the paths that ended on a light ----
             const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
             if (m != 0) {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             }
         }
     }
-    if (!photons && e_tail != e_head) process_emitted(e_tail - e_head);
+    if (FUSED && e_tail != e_head) process_emitted(e_tail - e_head);
     // One atomic per wave for the counters.
     uint32_t s = segments, d = paths_done;
 #pragma unroll
