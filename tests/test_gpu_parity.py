@@ -142,6 +142,27 @@ def test_plot_fused_and_unfused_match_oracle(demo):
     assert not p2.tristimulus_buffer.any()
 
 
+def test_plot_reads_photons_before_the_next_render_overwrites_them(demo):
+    """PlotUnit::plot is asynchronous on the plot unit's stream while the trace unit is handed out again
+    at once (task_scheduler.rs:262-271): the next render into the same mapped_photons must wait for the plot
+    kernel (rl_api.hip records an event the trace stream waits on).  Twenty render -> plot rounds back to back
+    must add up to the oracle's twenty plots."""
+    objs, cam, scene, oscene = demo
+    W, H, N, rounds = 96, 54, 1 << 16, 20
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    p = R.PlotUnit(0, W, H)
+    want = np.zeros((W * H, 3), np.float32)
+    for k in range(rounds):
+        t.render(scene, seed=21, stream=0, first_path_index=k * N)
+        p.plot([t])                                       # no host synchronisation before the next render
+    for k in range(rounds):
+        photons, _ = oscene.render(W, H, 21, 0, k * N, N, threads=8)
+        O.plot(W, H, photons, want)
+    got = p.tristimulus_buffer
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-6 * np.abs(want).max())
+    assert abs(float(got.sum(dtype=np.float64)) / float(want.sum(dtype=np.float64)) - 1) < 1e-6
+
+
 def test_gather_kahan_bit_exact_and_clears_plot(demo):
     objs, cam, scene, oscene = demo
     W, H, N = 160, 90, 1 << 16
