@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librobigo_luculenta.so")
+# RL_LIBRARY: a diagnostic build of the same library (e.g. `make -C csrc stats`); never a different implementation.
+LIB_PATH = os.environ.get("RL_LIBRARY") or os.path.join(HERE, "librobigo_luculenta.so")
 
 RL_TASK_MAX_UNITS = 64
 

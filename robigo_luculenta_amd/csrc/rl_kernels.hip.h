@@ -44,6 +44,22 @@ struct RlTraceJob {
     uint64_t n_paths;
 };
 
+// Diagnostic build only (make stats): wave-level event counters of the trace kernel, read back by
+// tools/kernel_stats.py.  RL_STAT(k, v) adds v to counter k once per wave (lane 0).
+#ifdef RL_STATS
+enum { RL_ST_ITER, RL_ST_SCAN_LANES, RL_ST_A_ROUNDS, RL_ST_A_LANES, RL_ST_B_ROUNDS, RL_ST_B_LANES, RL_ST_P_ROUNDS, RL_ST_P_LANES,
+       RL_ST_SHADE_DIFFUSE, RL_ST_SHADE_GLASS, RL_ST_SHADE_SOAP, RL_ST_END_EMITTER, RL_ST_END_VOID, RL_ST_ANY_GLASS, RL_ST_ANY_SOAP,
+       RL_ST_ANY_COLOURED, RL_ST_ANY_GLOSSY, RL_ST_REFILLS, RL_ST_EMIT_BATCHES, RL_ST_EMIT_LANES, RL_ST_A_ITEMS, RL_ST_P_ITEMS,
+       RL_ST_ANY_DIFFUSE, RL_ST_COUNT };
+__device__ unsigned long long rl_stat_counters[32];
+#define RL_STAT(K, V)                                                                                \
+    do {                                                                                             \
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&rl_stat_counters[K], (unsigned long long)(V));      \
+    } while (0)
+#else
+#define RL_STAT(K, V) do { } while (0)
+#endif
+
 typedef __attribute__((address_space(3))) unsigned long long RlLdsU64;
 typedef __attribute__((address_space(3))) uint32_t RlLdsU32;
 
@@ -167,6 +183,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 
     // ---- ring B round: exact sphere tail for (record position, owner) pairs ----
     auto process_spheres = [&](uint32_t count) {
+        RL_STAT(RL_ST_B_ROUNDS, 1);
+        RL_STAT(RL_ST_B_LANES, count);
         rl_wave_sync();
         const uint32_t e = ring_b[(b_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -234,6 +252,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 
     // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members ----
     auto process_clusters = [&](uint32_t count) {
+        RL_STAT(RL_ST_A_ROUNDS, 1);
+        RL_STAT(RL_ST_A_LANES, count);
         rl_wave_sync();
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -278,13 +298,19 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_CLUSTER_CULL
         if (a_tail != a_head) process_clusters(a_tail - a_head);
         a_head = a_tail;
+        RL_STAT(RL_ST_A_ITEMS, a_tail);
     }
+#ifdef RL_STATS
+    const uint32_t a_head_after_clusters = a_tail;
+#endif
 #undef RL_SPHERE_REJECT
     if (b_tail != b_head) process_spheres(b_tail - b_head);
     b_head = b_tail;
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
     auto process_prisms = [&](uint32_t count) {
+        RL_STAT(RL_ST_P_ROUNDS, 1);
+        RL_STAT(RL_ST_P_LANES, count);
         rl_wave_sync();
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -324,6 +350,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }
     }
     if (a_tail != a_head) process_prisms(a_tail - a_head);
+#ifdef RL_STATS
+    {
+        uint32_t cluster_items = 0;
+        if (sv.n_clusters != 0) cluster_items = a_head_after_clusters;
+        RL_STAT(RL_ST_P_ITEMS, a_tail - cluster_items);
+    }
+#endif
 
     rl_wave_sync();
     const unsigned long long k = keys[lane];
@@ -406,6 +439,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     // Evaluates and splats `count` queued paths, one per lane: EmissiveMaterial::get_intensity
     // (material.rs:101-105), cie1931::get_tristimulus and PlotUnit::plot_pixel (plot_unit.rs:56-84).
     auto process_emitted = [&](uint32_t count) {
+        RL_STAT(RL_ST_EMIT_BATCHES, 1);
+        RL_STAT(RL_ST_EMIT_LANES, count);
         rl_wave_sync();
         if (lane < count) {
             const uint32_t slot = (e_head + lane) & 127u;
@@ -448,6 +483,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     chunk_next = ((uint64_t)hi << 32) | lo;
                     chunk_end = chunk_next + chunk;
                 }
+                RL_STAT(RL_ST_REFILLS, 1);
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
                 const bool valid = offset < job.n_paths;
@@ -496,6 +532,31 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, p.origin, p.direction,
                                        active ? 0u : 0x80000000u, ws, lane);
+#ifdef RL_STATS
+        {
+            const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? (rl_f2u(sv.objects[2 * hit.obj].x) >> 8) : 99u;
+            const uint64_t m_act = __builtin_amdgcn_ballot_w64(active);
+            const uint64_t m_void = __builtin_amdgcn_ballot_w64(active && hit.obj == RL_HIT_NONE);
+            const uint64_t m_emit = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_BLACK_BODY);
+            const uint64_t m_grey = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_DIFFUSE_GREY);
+            const uint64_t m_col = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_DIFFUSE_COLOURED);
+            const uint64_t m_gls = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_GLOSSY_MIRROR);
+            const uint64_t m_glass = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_SF10_GLASS);
+            const uint64_t m_soap = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_SOAP_BUBBLE);
+            RL_STAT(RL_ST_ITER, 1);
+            RL_STAT(RL_ST_SCAN_LANES, __popcll(m_act));
+            RL_STAT(RL_ST_END_VOID, __popcll(m_void));
+            RL_STAT(RL_ST_END_EMITTER, __popcll(m_emit));
+            RL_STAT(RL_ST_SHADE_DIFFUSE, __popcll(m_grey | m_col | m_gls));
+            RL_STAT(RL_ST_SHADE_GLASS, __popcll(m_glass));
+            RL_STAT(RL_ST_SHADE_SOAP, __popcll(m_soap));
+            RL_STAT(RL_ST_ANY_DIFFUSE, (m_grey | m_col | m_gls) != 0);
+            RL_STAT(RL_ST_ANY_GLASS, m_glass != 0);
+            RL_STAT(RL_ST_ANY_SOAP, m_soap != 0);
+            RL_STAT(RL_ST_ANY_COLOURED, m_col != 0);
+            RL_STAT(RL_ST_ANY_GLOSSY, m_gls != 0);
+        }
+#endif
         if (active) {
             segments += 1;
             float value;

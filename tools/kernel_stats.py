@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Wave-level event counts of the trace kernel (diagnostic build `make -C robigo_luculenta_amd/csrc stats`,
+-DRL_STATS): how many compaction rounds of each kind an iteration runs and how full they are, which
+material branches a wave enters, how often the stash is refilled.  Sizes DESIGN.md's instruction budget.
+Usage (GPU box): python tools/kernel_stats.py [batches=16] [scene=demo|glass|replicated]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["RL_LIBRARY"] = os.path.join(ROOT, "robigo_luculenta_amd", "librobigo_luculenta_stats.so")
+sys.path.insert(0, ROOT)
+import robigo_luculenta_amd as R  # noqa: E402
+from robigo_luculenta_amd import _lib  # noqa: E402
+
+NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_rounds", "p_lanes", "shade_diffuse",
+         "shade_glass", "shade_soap", "end_emitter", "end_void", "any_glass", "any_soap", "any_coloured", "any_glossy",
+         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse"]
+
+batches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+which = sys.argv[2] if len(sys.argv) > 2 else "demo"
+objs, cam = {"demo": lambda: R.builtin_scene_desc(R.SCENE_DEMO), "glass": lambda: R.builtin_scene_desc(R.SCENE_GLASS_STRESS),
+             "replicated": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 158)}[which]()
+scene = R.Scene(objs, cam)
+t, plot = R.TraceUnit(0, 1920, 1080, n_photons=64), R.PlotUnit(0, 1920, 1080)
+read = _lib.lib.rl_stats_read
+read.restype, read.argtypes = C.c_int, [C.POINTER(C.c_uint64), C.c_int]
+buf = (C.c_uint64 * 32)()
+read(buf, 32)  # clear
+t.render_fused(scene, plot, batches * R.NUMBER_OF_PHOTONS, seed=1, stream=0, first_path_index=0)
+t.sync()
+assert read(buf, 32) == 0
+c = dict(zip(NAMES, list(buf)))
+paths, segs, ms = t.stats()
+it = float(c["iter"])
+print("%s: %d paths, %d rays, %d wave-iterations, %.1f rays per wave-iteration (of 64)" % (which, paths, segs, c["iter"], segs / it))
+print("  scan lanes active            %5.1f %%" % (100.0 * c["scan_lanes"] / (64 * it)))
+for key, label in (("a", "cluster-member rounds"), ("b", "sphere-tail rounds    "), ("p", "prism CSG rounds     ")):
+    r, l = c[key + "_rounds"], c[key + "_lanes"]
+    print("  %s  %.2f per iteration, %4.1f %% of lanes filled" % (label, r / it, 100.0 * l / max(1, 64 * r)))
+print("  (cluster, ray) pairs         %.1f per iteration = %.2f per ray;  (prism, ray) pairs %.1f = %.2f per ray"
+      % (c["a_items"] / it, c["a_items"] / float(c["scan_lanes"]), c["p_items"] / it, c["p_items"] / float(c["scan_lanes"])))
+hits = float(c["scan_lanes"])
+print("  outcome per ray: diffuse family %.1f %%, glass %.1f %%, soap %.1f %%, ended on a light %.1f %%, void %.1f %%"
+      % tuple(100.0 * c[k] / hits for k in ("shade_diffuse", "shade_glass", "shade_soap", "end_emitter", "end_void")))
+print("  iterations entering a branch: diffuse %.1f %%, glass %.1f %%, soap %.1f %%, coloured (f64 exp) %.1f %%, glossy %.1f %%"
+      % tuple(100.0 * c[k] / it for k in ("any_diffuse", "any_glass", "any_soap", "any_coloured", "any_glossy")))
+print("  stash refills %.3f per iteration; emitter batches %.3f per iteration, %.1f %% of lanes filled"
+      % (c["refills"] / it, c["emit_batches"] / it, 100.0 * c["emit_lanes"] / max(1, 64 * c["emit_batches"])))
