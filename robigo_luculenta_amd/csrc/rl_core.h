@@ -479,33 +479,44 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
             new_dir = rl_add(rl_mul(in_dir, ior), rl_mul(normal, ior * cos_i - cos_t));
         }
         probability = 1.0f;
-    } else if (material_kind == RL_MATERIAL_SOAP_BUBBLE) { // material.rs:267-305
-        const float cos_alpha = rl_dot(in_dir, is.normal);
-        if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = rl_reflect(in_dir, is.normal);
-        else new_dir = in_dir;
-        const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
-        const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
-        const float cos_theta = rl_clamp999(rl_dot(new_dir, is.tangent));
-        const float pc = rl_cosf(phase_shift - rl_acosf(cos_phi) * 3.0f - rl_acosf(cos_theta) * 2.0f + RL_PI_F * 0.5f);
-        probability = pc * 0.1f + 0.9f;
-    } else { // the diffuse family: material.rs:38-58 then :122-130 / :155-168 / :185-196
-        const float phi = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58
-        const float rq = rl_get_unit(rb.w[1]);
-        const float r = sqrtf(rq);
-        float sin_p, cos_p;
-        rl_sincosf(phi, &sin_p, &cos_p);
-        const RlF3 hemi = rl_f3(cos_p * r, sin_p * r, sqrtf(1.0f - rq));
-        const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
-        new_dir = rl_rotate_towards(hemi, facing);
-        probability = 1.0f;
-        if (material_kind == RL_MATERIAL_DIFFUSE_GREY) {
-            probability = ob.x;
-        } else if (material_kind == RL_MATERIAL_DIFFUSE_COLOURED) {
-            const float pw = (ob.y - p->wavelength) / ob.z;
-            probability = ob.x * rl_expf(-0.5f * pw * pw);
-        } else { // glossy mirror: blends with the mirror direction about the un-flipped normal
-            const RlF3 reflection = rl_reflect(in_dir, is.normal);
-            new_dir = rl_normalise(rl_add(rl_mul(new_dir, ob.x), rl_mul(reflection, 1.0f - ob.x)));
+    } else {
+        // Soap bubbles and the diffuse family each need one f64 sin/cos evaluation: the cosine of the film's
+        // phase (material.rs:293-294) and the hemisphere longitude (monte_carlo.rs:47-58).  A 64-wide wave
+        // holds both kinds in nearly every iteration (profiles/: 99 %), so the argument is selected per lane
+        // and rl_sincosf runs once for both; rl_cosf(x) is the cosine half of the same evaluation.
+        const bool soap = material_kind == RL_MATERIAL_SOAP_BUBBLE;
+        float angle;
+        if (soap) { // material.rs:267-305
+            const float cos_alpha = rl_dot(in_dir, is.normal);
+            if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = rl_reflect(in_dir, is.normal);
+            else new_dir = in_dir;
+            const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
+            const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
+            const float cos_theta = rl_clamp999(rl_dot(new_dir, is.tangent));
+            angle = phase_shift - rl_acosf(cos_phi) * 3.0f - rl_acosf(cos_theta) * 2.0f + RL_PI_F * 0.5f;
+        } else {
+            angle = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58
+        }
+        float sin_a, cos_a;
+        rl_sincosf(angle, &sin_a, &cos_a);
+        if (soap) {
+            probability = cos_a * 0.1f + 0.9f;
+        } else { // the diffuse family: material.rs:38-58 then :122-130 / :155-168 / :185-196
+            const float rq = rl_get_unit(rb.w[1]);
+            const float r = sqrtf(rq);
+            const RlF3 hemi = rl_f3(cos_a * r, sin_a * r, sqrtf(1.0f - rq));
+            const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
+            new_dir = rl_rotate_towards(hemi, facing);
+            probability = 1.0f;
+            if (material_kind == RL_MATERIAL_DIFFUSE_GREY) {
+                probability = ob.x;
+            } else if (material_kind == RL_MATERIAL_DIFFUSE_COLOURED) {
+                const float pw = (ob.y - p->wavelength) / ob.z;
+                probability = ob.x * rl_expf(-0.5f * pw * pw);
+            } else { // glossy mirror: blends with the mirror direction about the un-flipped normal
+                const RlF3 reflection = rl_reflect(in_dir, is.normal);
+                new_dir = rl_normalise(rl_add(rl_mul(new_dir, ob.x), rl_mul(reflection, 1.0f - ob.x)));
+            }
         }
     }
 
