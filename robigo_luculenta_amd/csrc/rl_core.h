@@ -46,10 +46,15 @@ RL_HD RlF3 rl_normalise(RlF3 v) {                                               
     return (m == 0.0f) ? v : u;
 }
 RL_HD RlF3 rl_reflect(RlF3 v, RlF3 n) { return rl_sub(v, rl_mul(rl_mul(n, 2.0f), rl_dot(n, v))); }   // vector3.rs:91-93
+RL_HD RlF3 rl_rotate_towards(RlF3 v, RlF3 n, RlF3 a1);
 RL_HD RlF3 rl_rotate_towards(RlF3 v, RlF3 n) {                                                       // vector3.rs:69-83
+    return rl_rotate_towards(v, n, rl_normalise(rl_cross(rl_f3(0.0f, 0.0f, 1.0f), n)));
+}
+// vector3.rs:69-83 with the first axis, a1 = normalise(cross((0, 0, 1), n)), supplied by the caller (rl_bounce
+// shares that normalisation with the soap bubble's tangent).
+RL_HD RlF3 rl_rotate_towards(RlF3 v, RlF3 n, RlF3 a1) {
     if (n.z > 0.9999f) return v;
     if (n.z < -0.9999f) return rl_f3(v.x, v.y, -v.z);
-    const RlF3 a1 = rl_normalise(rl_cross(rl_f3(0.0f, 0.0f, 1.0f), n));
     const RlF3 a2 = rl_normalise(rl_cross(a1, n));
     return rl_add(rl_add(rl_mul(a1, v.x), rl_mul(a2, v.y)), rl_mul(n, v.z));
 }
@@ -361,33 +366,35 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
 // ---- hit completion (geometry.rs:73-86,110-121,166-184,242-259,343-357) -------------------------
 
 struct RlIsect {
-    RlF3 position, normal, tangent;
+    RlF3 position, normal;
 };
 
-// `want_tangent`: only the soap bubble reads Intersection.tangent (material.rs:294); the reference
-// computes it for every sphere hit (geometry.rs:250-251), which is unobservable for other materials.
+// Intersection.tangent (geometry.rs:250-251) is not built here: only the soap bubble reads it
+// (material.rs:294), and rl_bounce derives it from the normal where it is needed.
+// The sphere's and the paraboloid's normals both end in a normalisation (sqrt + three IEEE divisions);
+// the un-normalised vector is selected per lane first so that a wave holding both kinds pays for one.
 RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit& hit, uint32_t surface_kind,
-                            uint32_t group_index, bool want_tangent) {
+                            uint32_t group_index) {
     RlIsect is;
     is.position = rl_add(o, rl_mul(dir, hit.t));
-    is.tangent = rl_f3(0.0f, 0.0f, 0.0f);
+    is.normal = rl_f3(0.0f, 0.0f, 0.0f);
+    RlF3 curved = rl_f3(0.0f, 0.0f, 0.0f);
     if (surface_kind == RL_SURFACE_SPHERE) {
-        const RlF4 s = sv.spheres[group_index];
-        is.normal = rl_normalise(rl_sub(is.position, rl_xyz(s)));
-        if (want_tangent) is.tangent = rl_normalise(rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal));
+        curved = rl_sub(is.position, rl_xyz(sv.spheres[group_index]));
     } else if (surface_kind == RL_SURFACE_PARABOLOID) {
         const RlF3 offset = rl_xyz(sv.parabs[3 * group_index]);
         const RlF3 normal = rl_xyz(sv.parabs[3 * group_index + 1]);
         const RlF3 focal_point = rl_xyz(sv.parabs[3 * group_index + 2]);
         const RlF3 local_pos = rl_sub(is.position, offset);
         const RlF3 plane_pr = rl_sub(local_pos, rl_mul(normal, rl_dot(local_pos, normal)));
-        is.normal = rl_normalise(rl_sub(focal_point, plane_pr));
+        curved = rl_sub(focal_point, plane_pr);
     } else if (surface_kind == RL_SURFACE_HEX_PRISM) {
         is.normal = rl_xyz(sv.prisms[RL_PRISM_STRIDE * group_index + 2 * hit.sub]); // SpacePartitioning: one-sided
     } else { // plane, circle: two-sided
         const RlF3 n = rl_xyz(sv.planes[2 * group_index]);
         is.normal = (rl_dot(n, dir) < 0.0f) ? n : rl_neg(n);
     }
+    if (surface_kind == RL_SURFACE_SPHERE || surface_kind == RL_SURFACE_PARABOLOID) is.normal = rl_normalise(curved);
     return is;
 }
 
@@ -454,8 +461,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         *emitter = hit.obj;
         return RL_PATH_ENDED_ON_EMITTER;
     }
-    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y),
-                                     material_kind == RL_MATERIAL_SOAP_BUBBLE);
+    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y));
     const RlRngBlock rb = rl_rng_block(seed, stream, path_index, 2u + p->bounce);
     const RlF3 in_dir = p->direction;
     RlF3 new_dir;
@@ -484,7 +490,14 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         // phase (material.rs:293-294) and the hemisphere longitude (monte_carlo.rs:47-58).  A 64-wide wave
         // holds both kinds in nearly every iteration (profiles/: 99 %), so the argument is selected per lane
         // and rl_sincosf runs once for both; rl_cosf(x) is the cosine half of the same evaluation.
+        // The same goes for a normalisation: the bubble's tangent normalise(cross((0, 1, 0), n)) -- spheres only,
+        // every other surface leaves it the zero vector (geometry.rs:250-251), which normalise returns
+        // unchanged -- and the first axis of rotate_towards, normalise(cross((0, 0, 1), facing)).
         const bool soap = material_kind == RL_MATERIAL_SOAP_BUBBLE;
+        const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
+        RlF3 axis = rl_cross(rl_f3(0.0f, 0.0f, 1.0f), facing);
+        if (soap) axis = surface_kind == RL_SURFACE_SPHERE ? rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal) : rl_f3(0.0f, 0.0f, 0.0f);
+        const RlF3 unit_axis = rl_normalise(axis);
         float angle;
         if (soap) { // material.rs:267-305
             const float cos_alpha = rl_dot(in_dir, is.normal);
@@ -492,7 +505,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
             else new_dir = in_dir;
             const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
             const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
-            const float cos_theta = rl_clamp999(rl_dot(new_dir, is.tangent));
+            const float cos_theta = rl_clamp999(rl_dot(new_dir, unit_axis)); // Intersection.tangent
             angle = phase_shift - rl_acosf(cos_phi) * 3.0f - rl_acosf(cos_theta) * 2.0f + RL_PI_F * 0.5f;
         } else {
             angle = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58
@@ -505,8 +518,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
             const float rq = rl_get_unit(rb.w[1]);
             const float r = sqrtf(rq);
             const RlF3 hemi = rl_f3(cos_a * r, sin_a * r, sqrtf(1.0f - rq));
-            const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
-            new_dir = rl_rotate_towards(hemi, facing);
+            new_dir = rl_rotate_towards(hemi, facing, unit_axis);
             probability = 1.0f;
             if (material_kind == RL_MATERIAL_DIFFUSE_GREY) {
                 probability = ob.x;
