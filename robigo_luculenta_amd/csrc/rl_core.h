@@ -464,6 +464,10 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
     const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y));
     const RlRngBlock rb = rl_rng_block(seed, stream, path_index, 2u + p->bounce);
     const RlF3 in_dir = p->direction;
+    // Mirror direction about the surface (vector3.rs:91-93): total internal reflection, the bubble's reflection
+    // and the glossy blend all use it, and flipping the normal (glass leaving the medium) changes no bit of it
+    // ((-a)(-b) == ab), so it is computed once for the wave instead of once per branch.
+    const RlF3 mirrored = rl_reflect(in_dir, is.normal);
     RlF3 new_dir;
     float probability;
 
@@ -479,7 +483,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         }
         const float sin_t_sqr = ior * ior * (1.0f - cos_i * cos_i);
         if (sin_t_sqr > 1.0f) {
-            new_dir = rl_reflect(in_dir, normal);
+            new_dir = mirrored;
         } else {
             const float cos_t = sqrtf(1.0f - sin_t_sqr);
             new_dir = rl_add(rl_mul(in_dir, ior), rl_mul(normal, ior * cos_i - cos_t));
@@ -501,7 +505,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         float angle;
         if (soap) { // material.rs:267-305
             const float cos_alpha = rl_dot(in_dir, is.normal);
-            if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = rl_reflect(in_dir, is.normal);
+            if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = mirrored;
             else new_dir = in_dir;
             const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
             const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
@@ -526,8 +530,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
                 const float pw = (ob.y - p->wavelength) / ob.z;
                 probability = ob.x * rl_expf(-0.5f * pw * pw);
             } else { // glossy mirror: blends with the mirror direction about the un-flipped normal
-                const RlF3 reflection = rl_reflect(in_dir, is.normal);
-                new_dir = rl_normalise(rl_add(rl_mul(new_dir, ob.x), rl_mul(reflection, 1.0f - ob.x)));
+                new_dir = rl_normalise(rl_add(rl_mul(new_dir, ob.x), rl_mul(mirrored, 1.0f - ob.x)));
             }
         }
     }
