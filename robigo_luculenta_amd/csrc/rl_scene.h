@@ -40,7 +40,7 @@ struct alignas(16) RlF4 {
 
 #define RL_PRISM_STRIDE 17 // records per hexagonal prism: 16 half-space records + 1 bound
 #ifndef RL_CLUSTER_K
-#define RL_CLUSTER_K 8                         // spheres per cluster (tuned on MI355X: DESIGN.md)
+#define RL_CLUSTER_K 10                        // spheres per cluster (tuned on MI355X: DESIGN.md)
 #endif
 #define RL_CLUSTER_STRIDE (RL_CLUSTER_K + 1)   // + the bound record in front (odd stride: LDS banks)
 
