@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void mb(float* out, float a, float b) {
             if (MODE == 22) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x[i]) : "v"(a), "v"(b) : "vcc");
             if (MODE == 23) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[i]) : "s"(b));
             if (MODE == 24) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[i]) : "v"(a), "v"(b));
+            if (MODE == 25) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, 0" : "=v"(*(unsigned long long*)&p[i]) : "v"(x[i]), "v"(a) : "s10", "s11");
+            if (MODE == 26) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
         }
     }
     float s = 0;
@@ -105,6 +107,8 @@ int main() {
         run<22>("cndmask 3reg", 1, w);
         run<23>("v_sub_f32 s-arg", 1, w);
         run<24>("v_fma acc", 2, w);
+        run<25>("v_mad_u64_u32", 1, w);
+        run<26>("v_xor_b32", 1, w);
     }
     return 0;
 }
