@@ -27,7 +27,7 @@ BATCH = 1024 * 512  # trace_unit.rs:67
 FLOPS_SPHERE, FLOPS_PARABOLOID, FLOPS_PLANE = 19, 38, 14
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
 # HBM-side bytes per traced path of rl_trace_kernel from the committed PMC passes of this same command
-# (profiles/r01l_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE) KB per 134,217,728-path launch); the
+# (profiles/r01m_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE) KB per 134,217,728-path launch); the
 # counters cannot be read from inside this process, so `roofline.traffic` scales that measurement.
 PROFILED_TRAFFIC_BYTES_PER_PATH = (2 * 482.4 + 5.308e6) * 1024 / 134217728
 
@@ -240,9 +240,9 @@ def main():
                                          "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms,
                          "algorithmic_flops_per_ray": f_seg,
-                         "valu_busy_profiled": 0.95, "active_lanes_profiled": 0.72,
+                         "valu_busy_profiled": 0.95, "active_lanes_profiled": 0.71,
                          "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only; "
-                                 "valu_busy / active_lanes from the PMC passes in profiles/r01l_pmc_summary.txt"},
+                                 "valu_busy / active_lanes from the PMC passes in profiles/r01m_pmc_summary.txt"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, cam, W, H)
