@@ -28,6 +28,14 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+} // namespace
+
+// Internal (not in the C header): lets rl_app.cpp hand a worker thread's error message to the thread that
+// called rl_app_run -- rl_last_error() is per thread.
+void rl_internal_set_last_error(const std::string& msg) { g_error = msg; }
+
+namespace {
+
 #define RL_HIP(call)                                                                                        \
     do {                                                                                                    \
         hipError_t e_ = (call);                                                                             \

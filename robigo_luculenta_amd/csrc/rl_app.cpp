@@ -19,6 +19,8 @@
 
 #include "../../include/robigo_luculenta.h"
 
+void rl_internal_set_last_error(const std::string& msg); // rl_api.hip
+
 namespace {
 
 struct AppState {
@@ -34,7 +36,6 @@ struct AppState {
     uint64_t traces_issued = 0;            // under `lock`
     std::atomic<uint64_t> fused_next_path{0}; // fused mode: next unrendered path index
     std::vector<uint64_t> trace_first_path; // per trace unit: the path range of its current task
-    std::vector<int> trace_target_plot;    // fused mode: plot unit that received the unit's photons (-1 none)
     uint64_t tasks[5] = {0, 0, 0, 0, 0};
     uint32_t tonemaps = 0;
     std::atomic<int> error{0};
@@ -244,7 +245,10 @@ void worker(AppState* ap) {
 } // namespace
 
 extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out) {
-    if (!config || config->width == 0 || config->height == 0 || config->concurrency == 0) return RL_E_INVALID;
+    if (!config || config->width == 0 || config->height == 0 || config->concurrency == 0) {
+        rl_internal_set_last_error("rl_app_run: null config, zero-sized image or zero workers");
+        return RL_E_INVALID;
+    }
     AppState a;
     a.cfg = config;
     a.photons = config->photons_per_batch ? config->photons_per_batch : 1024u * 512u;
@@ -288,7 +292,6 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
         }
     }
     a.trace_first_path.assign(n_trace, 0);
-    a.trace_target_plot.assign(n_trace, -1);
 
     if (rc == RL_OK) {
         a.t0 = std::chrono::steady_clock::now();
@@ -359,6 +362,6 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
     rl_tonemap_unit_destroy(a.tonemap);
     rl_scene_destroy(a.scene);
     rl_scheduler_destroy(a.scheduler);
-    (void)message;
+    if (rc != RL_OK && !message.empty()) rl_internal_set_last_error(message); // the failing call ran on a worker thread
     return rc;
 }

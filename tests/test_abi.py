@@ -66,6 +66,18 @@ def test_compute_entry_points_fail_loudly_without_a_device():
             ctor()
 
 
+def test_app_reports_errors_with_a_message():
+    """rl_app_run runs its tasks on worker threads; the message of whatever failed must reach the caller's
+    rl_last_error() (per thread), and argument errors must carry one too."""
+    with pytest.raises(R.RlError) as e:
+        R.app_run(0, 36, 1)
+    assert "zero" in str(e.value)
+    if R.device_count() == 0:
+        with pytest.raises(R.RlError) as e:
+            R.app_run(64, 36, 1)
+        assert "device" in str(e.value).lower()
+
+
 def test_invalid_arguments_return_codes_not_crashes():
     h = C.c_void_p()
     assert _lib.lib.rl_scheduler_create(0, 30000, C.byref(h)) == -1
