@@ -748,10 +748,10 @@ int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n
 #ifdef RL_STATS
 // Diagnostic build only (not in the header): copies and clears the trace kernel's event counters.
 int rl_stats_read(unsigned long long* out, int n) {
-    unsigned long long host[32];
+    unsigned long long host[48];
     if (hipDeviceSynchronize() != hipSuccess) return RL_E_HIP;
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(rl_stat_counters), sizeof host) != hipSuccess) return RL_E_HIP;
-    for (int i = 0; i < n && i < 32; ++i) out[i] = host[i];
+    for (int i = 0; i < n && i < 48; ++i) out[i] = host[i];
     std::memset(host, 0, sizeof host);
     if (hipMemcpyToSymbol(HIP_SYMBOL(rl_stat_counters), host, sizeof host) != hipSuccess) return RL_E_HIP;
     return RL_OK;

@@ -50,14 +50,32 @@ struct RlTraceJob {
 enum { RL_ST_ITER, RL_ST_SCAN_LANES, RL_ST_A_ROUNDS, RL_ST_A_LANES, RL_ST_B_ROUNDS, RL_ST_B_LANES, RL_ST_P_ROUNDS, RL_ST_P_LANES,
        RL_ST_SHADE_DIFFUSE, RL_ST_SHADE_GLASS, RL_ST_SHADE_SOAP, RL_ST_END_EMITTER, RL_ST_END_VOID, RL_ST_ANY_GLASS, RL_ST_ANY_SOAP,
        RL_ST_ANY_COLOURED, RL_ST_ANY_GLOSSY, RL_ST_REFILLS, RL_ST_EMIT_BATCHES, RL_ST_EMIT_LANES, RL_ST_A_ITEMS, RL_ST_P_ITEMS,
-       RL_ST_ANY_DIFFUSE, RL_ST_COUNT };
-__device__ unsigned long long rl_stat_counters[32];
+       RL_ST_ANY_DIFFUSE,
+       // shader cycles (s_memtime) a wave spent in each region of the main loop, summed over waves
+       RL_ST_T_TOTAL, RL_ST_T_REFILL, RL_ST_T_SMALL, RL_ST_T_DIRECT, RL_ST_T_CLUSTER, RL_ST_T_TAIL, RL_ST_T_PRISM, RL_ST_T_SHADE,
+       RL_ST_T_EMIT, RL_ST_T_A_ROUNDS, RL_ST_T_B_ROUNDS, RL_ST_T_P_ROUNDS, RL_ST_T_CAMERA, RL_ST_COUNT };
+__device__ unsigned long long rl_stat_counters[48];
+// asm volatile + "memory": ordered against every LDS access, barrier and other timer read (the builtin may be
+// hoisted or sunk by the optimiser); pure ALU work may still drift across a read by a few instructions.
+__device__ __forceinline__ unsigned long long rl_cycles() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#define RL_T0(V) const unsigned long long V = rl_cycles()
+#define RL_T1(K, V) tacc[(K) - RL_ST_T_TOTAL] += rl_cycles() - (V)
+#define RL_TACC_PARAM , unsigned long long* tacc
+#define RL_TACC_ARG , tacc
 #define RL_STAT(K, V)                                                                                \
     do {                                                                                             \
         if ((threadIdx.x & 63u) == 0) atomicAdd(&rl_stat_counters[K], (unsigned long long)(V));      \
     } while (0)
 #else
 #define RL_STAT(K, V) do { } while (0)
+#define RL_T0(V) do { } while (0)
+#define RL_T1(K, V) do { } while (0)
+#define RL_TACC_PARAM
+#define RL_TACC_ARG
 #endif
 
 typedef __attribute__((address_space(3))) unsigned long long RlLdsU64;
@@ -141,7 +159,7 @@ struct RlWaveScratch {
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2, RlF3 o, RlF3 dir,
-                                              uint32_t idle_bit, RlWaveScratch* ws, uint32_t lane) {
+                                              uint32_t idle_bit, RlWaveScratch* ws, uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
     RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
@@ -154,6 +172,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     best.t = 1.0e12f; // scene.rs:43
     best.obj = RL_HIT_NONE;
     best.sub = 0;
+    RL_T0(t_small);
     for (uint32_t i = 0; i < sv.n_parabs; ++i) {
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
@@ -180,11 +199,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     }
     keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) |
                  (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
+    RL_T1(RL_ST_T_SMALL, t_small);
 
     // ---- ring B round: exact sphere tail for (record position, owner) pairs ----
     auto process_spheres = [&](uint32_t count) {
         RL_STAT(RL_ST_B_ROUNDS, 1);
         RL_STAT(RL_ST_B_LANES, count);
+        RL_T0(t_b);
         rl_wave_sync();
         const uint32_t e = ring_b[(b_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -207,6 +228,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             }
         }
         rl_wave_sync();
+        RL_T1(RL_ST_T_B_ROUNDS, t_b);
     };
 
     // Reject test of one sphere record S for the ray (OX.., DX..); survivors go to ring B as
@@ -232,6 +254,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 
     // ---- direct spheres: every ray against every record; groups of 4 with one group of prefetch, then
     // the remainder one by one (the padding of rl_scene.h keeps every prefetch in bounds) ----
+    RL_T0(t_direct);
     if (sv.n_direct != 0) {
         const uint32_t full = sv.n_direct & ~3u;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
@@ -249,11 +272,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             c0 = next;
         }
     }
+    RL_T1(RL_ST_T_DIRECT, t_direct);
 
     // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members ----
     auto process_clusters = [&](uint32_t count) {
         RL_STAT(RL_ST_A_ROUNDS, 1);
         RL_STAT(RL_ST_A_LANES, count);
+        RL_T0(t_a);
         rl_wave_sync();
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -269,8 +294,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             s = s_next;
         }
         rl_wave_sync();
+        RL_T1(RL_ST_T_A_ROUNDS, t_a);
     };
 
+    RL_T0(t_cluster);
     const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
     // ---- sphere clusters: bound cull per ray -> ring A ----
     if (sv.n_clusters != 0) { // even count (rl_scene.cpp pads), two clusters per iteration
@@ -304,13 +331,18 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     const uint32_t a_head_after_clusters = a_tail;
 #endif
 #undef RL_SPHERE_REJECT
+    RL_T1(RL_ST_T_CLUSTER, t_cluster);
+    RL_T0(t_tail);
     if (b_tail != b_head) process_spheres(b_tail - b_head);
     b_head = b_tail;
+    RL_T1(RL_ST_T_TAIL, t_tail);
+    RL_T0(t_prism);
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
     auto process_prisms = [&](uint32_t count) {
         RL_STAT(RL_ST_P_ROUNDS, 1);
         RL_STAT(RL_ST_P_LANES, count);
+        RL_T0(t_p);
         rl_wave_sync();
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
@@ -332,6 +364,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             }
         }
         rl_wave_sync();
+        RL_T1(RL_ST_T_P_ROUNDS, t_p);
     };
     const RlF4* pcull = cull + sv.n_clusters;
     RlF4 pb = pcull[0];
@@ -350,6 +383,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }
     }
     if (a_tail != a_head) process_prisms(a_tail - a_head);
+    RL_T1(RL_ST_T_PRISM, t_prism);
 #ifdef RL_STATS
     {
         uint32_t cluster_items = 0;
@@ -435,6 +469,11 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     uint32_t e_head = 0, e_tail = 0; // wave-uniform ring indices of the emitter queue
     bool ended_on_emitter = false;
     uint32_t emit_obj = 0;
+#ifdef RL_STATS
+    unsigned long long tacc[RL_ST_COUNT - RL_ST_T_TOTAL];
+    for (int k = 0; k < RL_ST_COUNT - RL_ST_T_TOTAL; ++k) tacc[k] = 0;
+#endif
+    RL_T0(t_total);
 
     // Evaluates and splats `count` queued paths, one per lane: EmissiveMaterial::get_intensity
     // (material.rs:101-105), cie1931::get_tristimulus and PlotUnit::plot_pixel (plot_unit.rs:56-84).
@@ -463,6 +502,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
 
     for (;;) {
         // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
+        RL_T0(t_refill);
         for (;;) {
             const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
             if (need == 0) break;
@@ -488,7 +528,9 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 chunk_next += 64;
                 const bool valid = offset < job.n_paths;
                 RlPath fresh = p;
+                RL_T0(t_cam);
                 if (valid) rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, job.first_path + offset, &fresh);
+                RL_T1(RL_ST_T_CAMERA, t_cam);
                 rl_wave_sync();
                 stash[0 * 64 + lane] = fresh.origin.x;
                 stash[1 * 64 + lane] = fresh.origin.y;
@@ -529,9 +571,10 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             const uint32_t wanted = (uint32_t)__popcll(need);
             stash_head += wanted < avail ? wanted : avail;
         }
+        RL_T1(RL_ST_T_REFILL, t_refill);
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
         const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, p.origin, p.direction,
-                                       active ? 0u : 0x80000000u, ws, lane);
+                                       active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
             const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? (rl_f2u(sv.objects[2 * hit.obj].x) >> 8) : 99u;
@@ -557,6 +600,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             RL_STAT(RL_ST_ANY_GLOSSY, m_gls != 0);
         }
 #endif
+        RL_T0(t_shade);
         if (active) {
             segments += 1;
             float value;
@@ -580,6 +624,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 }
             }
         }
+        RL_T1(RL_ST_T_SHADE, t_shade);
+        RL_T0(t_emit);
         if (FUSED) {
             // ---- fused splat (plot_unit.rs:56-95), deferred: queue the paths that ended on a light ----
             const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
@@ -600,8 +646,13 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 }
             }
         }
+        RL_T1(RL_ST_T_EMIT, t_emit);
     }
     if (FUSED && e_tail != e_head) process_emitted(e_tail - e_head);
+    RL_T1(RL_ST_T_TOTAL, t_total);
+#ifdef RL_STATS
+    for (int k = 0; k < RL_ST_COUNT - RL_ST_T_TOTAL; ++k) RL_STAT(RL_ST_T_TOTAL + k, tacc[k]);
+#endif
     // One atomic per wave for the counters.
     uint32_t s = segments, d = paths_done;
 #pragma unroll

@@ -15,7 +15,9 @@ from robigo_luculenta_amd import _lib  # noqa: E402
 
 NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_rounds", "p_lanes", "shade_diffuse",
          "shade_glass", "shade_soap", "end_emitter", "end_void", "any_glass", "any_soap", "any_coloured", "any_glossy",
-         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse"]
+         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse",
+         "t_total", "t_refill", "t_small", "t_direct", "t_cluster", "t_tail", "t_prism", "t_shade", "t_emit", "t_a_rounds",
+         "t_b_rounds", "t_p_rounds", "t_camera"]
 
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 which = sys.argv[2] if len(sys.argv) > 2 else "demo"
@@ -25,11 +27,11 @@ scene = R.Scene(objs, cam)
 t, plot = R.TraceUnit(0, 1920, 1080, n_photons=64), R.PlotUnit(0, 1920, 1080)
 read = _lib.lib.rl_stats_read
 read.restype, read.argtypes = C.c_int, [C.POINTER(C.c_uint64), C.c_int]
-buf = (C.c_uint64 * 32)()
-read(buf, 32)  # clear
+buf = (C.c_uint64 * 48)()
+read(buf, 48)  # clear
 t.render_fused(scene, plot, batches * R.NUMBER_OF_PHOTONS, seed=1, stream=0, first_path_index=0)
 t.sync()
-assert read(buf, 32) == 0
+assert read(buf, 48) == 0
 c = dict(zip(NAMES, list(buf)))
 paths, segs, ms = t.stats()
 it = float(c["iter"])
@@ -47,3 +49,16 @@ print("  iterations entering a branch: diffuse %.1f %%, glass %.1f %%, soap %.1f
       % tuple(100.0 * c[k] / it for k in ("any_diffuse", "any_glass", "any_soap", "any_coloured", "any_glossy")))
 print("  stash refills %.3f per iteration; emitter batches %.3f per iteration, %.1f %% of lanes filled"
       % (c["refills"] / it, c["emit_batches"] / it, 100.0 * c["emit_lanes"] / max(1, 64 * c["emit_batches"])))
+# Where a wave's cycles go (s_memtime around each region of the main loop, summed over all waves; the
+# reads themselves wait for outstanding LDS/scalar loads, so this build runs ~10 % slower than the product).
+tt = float(c["t_total"])
+if tt > 0:
+    print("  wave cycles per iteration %.0f (shader clock); share of a wave's time by region:" % (tt / it))
+    rows = (("refill (stash hand-out + camera rays)", "t_refill"), ("  of which rl_begin_path", "t_camera"),
+            ("planes / circles / paraboloids", "t_small"), ("direct spheres", "t_direct"),
+            ("cluster culls + member rounds", "t_cluster"), ("  of which member rounds", "t_a_rounds"),
+            ("final sphere-tail flush", "t_tail"), ("  all sphere-tail rounds", "t_b_rounds"),
+            ("prism culls + CSG rounds", "t_prism"), ("  of which CSG rounds", "t_p_rounds"),
+            ("bounce (hit completion, material, roulette)", "t_shade"), ("emitter queue + splat", "t_emit"))
+    for label, key in rows:
+        print("    %-46s %5.1f %%  (%6.0f cycles per iteration)" % (label, 100.0 * c[key] / tt, c[key] / it))
