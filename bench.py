@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s of the fused trace+plot hot path on the built-in scene.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one fused TraceUnit::render + PlotUnit::plot launch over `--batches-per-step` (default 256) batches
-of 524,288 camera paths (trace_unit.rs:67) of the built-in demo scene (app.rs:166-363), followed,
-every `--gather-every` steps, by the GatherUnit step (Kahan accumulate + clear; with N > 1 the XYZ
-plot buffers are first sum-reduced to rank 0 over RCCL).  Every rank renders the full frame with its
-own RNG stream (stream = rank) -- samples shard, nothing else is exchanged -- so per-GPU work is
-fixed as N grows ("weak").  A ray = one Scene::intersect call (one path segment, scene.rs:39),
-counted on the device.  Prints ONE JSON line on rank 0.
+One "step" = `--launches-per-step` (8) fused TraceUnit::render + PlotUnit::plot launches of `--batches-per-launch`
+(256) batches of 524,288 camera paths each (trace_unit.rs:67) on the built-in demo scene (app.rs:166-363), then the
+GatherUnit step: with N > 1 the ranks' XYZ plot buffers are summed onto rank 0 by the library's own RCCL exchange
+(rl_plot_unit_reduce: one ncclReduce over xGMI), rank 0 Kahan-accumulates and every rank clears
+(gather_unit.rs:49-64, app.rs:147).  Every rank renders the full frame with its own RNG stream (stream = rank) --
+samples shard, nothing else is exchanged -- so per-GPU work is fixed as N grows ("weak").  A ray = one
+Scene::intersect call (one path segment, scene.rs:39), counted on the device.  Rank 0 prints ONE JSON line.
+
+torch is not used for device work at all: N = 1 never imports it, and N > 1 uses torch.distributed (gloo) only for
+the control plane (communicator id, barriers, max/sum of timings; robigo_luculenta_amd/distributed.py).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,10 +32,10 @@ BATCH = 1024 * 512  # trace_unit.rs:67
 # (SURVEY 8d): sphere 19, paraboloid 38, plane / circle / half-space 14.
 FLOPS_SPHERE, FLOPS_PARABOLOID, FLOPS_PLANE = 19, 38, 14
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
-# HBM-side bytes per traced path of rl_trace_kernel from the committed PMC passes of this same command
-# (profiles/r01m_pmc_summary.txt: (2*FETCH_SIZE + WRITE_SIZE) KB per 134,217,728-path launch); the
-# counters cannot be read from inside this process, so `roofline.traffic` scales that measurement.
-PROFILED_TRAFFIC_BYTES_PER_PATH = (2 * 482.4 + 5.308e6) * 1024 / 134217728
+# Wave64 VALU issue interval of a plain mul/add/sub stream (the op mix the reference arithmetic allows) at the trace
+# kernel's occupancy of 4 waves per SIMD, measured in shader cycles: profiles/r02_valu_microbench.txt ("mul/add/sub
+# mix", w/SIMD = 4, wall c/i).  MI355X_MICROARCH.md's nominal figure is 2.
+MEASURED_STREAM_CYCLES_4_WAVES = 2.7
 
 CONFIGS = {
     # name: (scene, param, width, height)
@@ -43,6 +49,8 @@ CONFIGS = {
     "ablate-seeds": ("demo[:207]", 0, 1920, 1080),
     "ablate-allgrey": ("demo[grey]", 0, 1920, 1080),  # every reflective material -> DiffuseGrey(0.8)
 }
+# The other BASELINE configs, timed briefly in the default N = 1 run and reported under config.others.
+OTHERS = (("demo-720p", "lds"), ("glass-720p", "lds"), ("replicated-1080p", "lds"), ("replicated-1080p", "global"))
 
 
 def flops_per_ray(objs):
@@ -69,9 +77,10 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(objs, cam, width, height, seconds_target=15.0):
-    """Times the CPU oracle (C++ restatement of the Rust reference; the Rust crate cannot be built
-    here: no rustc/cargo) on this box's host cores over a bounded sample of the same workload."""
+def cpu_baseline(objs, cam, width, height, seconds_target=30.0):
+    """Times the CPU oracle (C++ restatement of the Rust reference, built -O3 without fast-math; the Rust crate
+    cannot be built here: no rustc/cargo) on this box's host cores over a bounded sample of the same workload:
+    >= 30 s on every usable core, then ~3 s on one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     threads = usable_cores()
@@ -81,59 +90,20 @@ def cpu_baseline(objs, cam, width, height, seconds_target=15.0):
     # calibrate on a small slice, then size the sample for ~seconds_target
     n0 = 20000 * threads
     dt0 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, 0, n0, None, C.byref(segs), threads)
-    n = int(max(n0, min(n0 * seconds_target / max(dt0, 1e-3), 64 * BATCH)))
+    n = int(max(n0, min(n0 * seconds_target * 1.05 / max(dt0, 1e-3), 256 * BATCH)))
     dt = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0, n, None, C.byref(segs), threads)
-    segs1 = C.c_uint64(0)                     # the 1-thread number beside it (~3 s)
+    segs1 = C.c_uint64(0)
     n1 = max(20000, int(n / threads * 3.0 / max(dt, 1e-3)))
     dt1 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0 + n, n1, None, C.byref(segs1), 1)
     return {"value": segs.value / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "one_thread": {"value": segs1.value / dt1 / 1e6, "unit": "Mrays/s", "sample": "%d paths, %.1f s" % (n1, dt1)},
-            "sample": "%d camera paths (%d rays) of the same scene/resolution, seed 1, %d threads, %.1f s"
+            "sample": "%d camera paths (%d rays) of the same scene/resolution, seed 1, %d threads, %.1f s; oracle built -O3"
                       % (n, segs.value, threads, dt),
             "mpaths_per_s": n / dt / 1e6, "batches_per_s": n / dt / BATCH}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="demo-1080p", choices=sorted(CONFIGS))
-    ap.add_argument("--batches-per-step", type=int, default=256)
-    ap.add_argument("--gather-every", type=int, default=2)
-    ap.add_argument("--fetch", default="lds", choices=["lds", "global"])
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl = RCCL over xGMI (default); gloo stages the XYZ reduce through host memory and lets several "
-                         "ranks share one GPU -- only for exercising the N > 1 code path on a 1-GPU box")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-
-    import numpy as np
-    import torch  # first: our library must share torch's HIP runtime (same SONAME) to share device pointers
-    import torch.distributed as dist
-    import robigo_luculenta_amd as R
-
-    if R.device_count() < 1 or not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    device = local_rank % R.device_count() if args.dist_backend == "gloo" else local_rank
-    torch.cuda.set_device(device)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    on_device = args.dist_backend == "nccl"
-
-    scene_name, param, W, H = CONFIGS[args.config]
+def scene_of(R, config):
+    scene_name, param, W, H = CONFIGS[config]
     which = R.SCENE_DEMO if scene_name.startswith("demo") else R.SCENE_GLASS_STRESS
     objs, cam = R.builtin_scene_desc(which, param)
     if "[grey]" in scene_name:
@@ -143,76 +113,210 @@ def main():
         objs["m"][refl] = (0.8, 0, 0)
     if "[:" in scene_name:
         objs = objs[: int(scene_name.split("[:")[1].rstrip("]"))].copy()
+    label = scene_name if param == 0 else "%s(seeds=%d)" % (scene_name, param)
+    return objs, cam, W, H, label
+
+
+def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms):
+    """The counter-derived half of the roofline, from the newest committed profiles/*_pmc.json that was measured
+    on THIS build of the library and this workload (rl_build_id: a hash of the device code's sources).  The
+    counters cannot be read from inside the process, so they come from the rocprofv3 --pmc passes of this same
+    command (tools/profile_round.sh); a profile of another build is refused rather than quoted."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("config") != config or d.get("fetch") != fetch:
+            continue
+        if d.get("build_id") == R.build_id() or best is None or best[1].get("build_id") != R.build_id():
+            best = (path, d)   # the newest profile of this build, else the newest of any build (reported as stale)
+    if best is None:
+        return {"stale": True, "reason": "no profiles/*_pmc.json for config %s / fetch %s" % (config, fetch)}
+    path, d = best
+    if d.get("build_id") != R.build_id():
+        return {"stale": True, "reason": "%s was measured on build %s, this library is build %s: counters not quoted"
+                                         % (os.path.relpath(path, ROOT), d.get("build_id"), R.build_id())}
+    c = d["counters"]
+    segs64 = d["rays_per_launch"] / 64.0
+    simds = 1024.0
+    cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / simds)
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    out = {
+        "profile": os.path.relpath(path, ROOT), "build_id": d["build_id"],
+        "valu_insts_per_64ray_segment": c["SQ_INSTS_VALU"] / segs64,
+        "cycles_per_valu_inst_per_simd": cyc,
+        "issue_frac_vs_2cyc": 2.0 / cyc,
+        "issue_frac_vs_measured_stream": MEASURED_STREAM_CYCLES_4_WAVES / cyc,
+        "active_lanes": lanes,
+        "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
+        "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
+        "lds_bank_conflict_share_of_lds_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]) if c.get("SQ_ACTIVE_INST_LDS") else None,
+        "wave_time": ({"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                       "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]} if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None),
+        "profiled_launch_ms": d["kernel_ns"] / 1e6, "profiled_rays_per_launch": d["rays_per_launch"],
+        "rays_per_launch_match": abs(d["rays_per_launch"] - rays_per_launch) <= 1e-6 * rays_per_launch,
+    }
+    traffic = None
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # MI355X_MICROARCH.md: FETCH_SIZE halves wide reads on gfx950
+    return out, traffic
+
+
+def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches, seed, device):
+    """Times `launches` fused launches of one config; returns the per-launch figures."""
+    objs, cam, W, H, label = scene_of(R, config)
+    scene = R.Scene(objs, cam, device=device)
+    trace = R.TraceUnit(rank, W, H, n_photons=64, device=device)
+    trace.set_fetch(R.FETCH_LDS if fetch == "lds" else R.FETCH_GLOBAL)
+    plot = R.PlotUnit(rank, W, H, device=device)
+    n = batches_per_launch * BATCH
+    nxt = 0
+    for _ in range(warm_launches):
+        trace.render_fused(scene, plot, n, seed=seed, stream=rank, first_path_index=nxt)
+        nxt += n
+    trace.sync()
+    p0, s0, ms0 = trace.stats()
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        trace.render_fused(scene, plot, n, seed=seed, stream=rank, first_path_index=nxt)
+        nxt += n
+    trace.sync()
+    t1 = time.perf_counter()
+    p1, s1, ms1 = trace.stats()
+    f_seg = flops_per_ray(objs)
+    launch_ms = (ms1 - ms0) / launches
+    achieved = (s1 - s0) / launches * f_seg / (launch_ms * 1e-3) / 1e12
+    return {"config": config, "workload": "built-in %s scene (%d objects), %dx%d, primitives in %s, %d launches of %d batches"
+            % (label, len(objs), W, H, "LDS" if fetch == "lds" else "global/scalar cache", launches, batches_per_launch),
+            "value": (s1 - s0) / (t1 - t0) / 1e6, "unit": "Mrays/s", "mpaths_per_s": (p1 - p0) / (t1 - t0) / 1e6,
+            "kernel_ms_per_launch": launch_ms, "algorithmic_flops_per_ray": f_seg,
+            "roofline_algorithmic": {"achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": achieved / PEAK_FP32_VECTOR_TFLOPS}}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the same environment contract
+    torch.distributed.run sets up), relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RL_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="demo-1080p", choices=sorted(CONFIGS))
+    ap.add_argument("--launches-per-step", type=int, default=8)
+    ap.add_argument("--batches-per-launch", type=int, default=256)
+    ap.add_argument("--fetch", default="lds", choices=["lds", "global"])
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configs (config.others)")
+    ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "gloo"],
+                    help="rccl = the library's ncclReduce over xGMI, one rank per GPU (default); gloo = the same sum staged "
+                         "through host memory, ranks may share a GPU -- for exercising the N > 1 path on a 1-GPU box")
+    args = ap.parse_args()
+
+    from robigo_luculenta_amd import distributed as D
+    rank, local_rank, world = D.env_rank()
+    if world == 1 and args.gpus > 1:
+        return spawn_ranks(args)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    if world > 1:
+        import torch  # noqa: F401  control plane only; imported before the library so that one HIP/RCCL copy is shared
+    import robigo_luculenta_amd as R
+
+    if R.device_count() < 1:
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    device = local_rank % R.device_count() if args.dist_backend == "gloo" else local_rank
+    D.init_control_plane(rank, world)
+    comm = None
+    if world > 1 and args.dist_backend == "rccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        comm = D.make_comm(R, rank, world, device)
+
+    objs, cam, W, H, label = scene_of(R, args.config)
     scene = R.Scene(objs, cam, device=device)
     trace = R.TraceUnit(rank, W, H, n_photons=64, device=device)  # fused mode does not use mapped_photons
     trace.set_fetch(R.FETCH_LDS if args.fetch == "lds" else R.FETCH_GLOBAL)
-    xyz = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")  # PlotUnit.tristimulus_buffer, reducible by RCCL
-    plot = R.PlotUnit(rank, W, H, device=device, external_xyz=xyz.data_ptr())
-    gather = R.GatherUnit(W, H, device=device)
-    paths_per_step = args.batches_per_step * BATCH
-
+    plot = R.PlotUnit(rank, W, H, device=device)
+    gather = R.GatherUnit(W, H, device=device) if rank == 0 else None
+    paths_per_launch = args.batches_per_launch * BATCH
     next_path = [0]
 
-    def step(i):
-        trace.render_fused(scene, plot, paths_per_step, seed=args.seed, stream=rank, first_path_index=next_path[0])
-        next_path[0] += paths_per_step
-        if (i + 1) % args.gather_every == 0:
-            trace.sync()
-            if world > 1 and on_device:
-                dist.reduce(xyz, dst=0, op=dist.ReduceOp.SUM)  # GatherUnit-time exchange over xGMI
-            elif world > 1:
-                host = xyz.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    xyz.copy_(host)
-            if rank == 0:
-                gather.accumulate(plot)   # Kahan + clear (gather_unit.rs:49-64, app.rs:147)
+    def gather_step():
+        """Task::Gather on `world` ranks (app.rs:143-148)."""
+        if comm is not None:
+            R.gather_allreduce(gather, plot, comm)   # rl_gather_unit_allreduce: ncclReduce onto rank 0, Kahan there, clear elsewhere
+        elif world > 1:   # host-staged: download, gloo sum, upload on the root
+            host = plot.tristimulus_buffer
+            if D.host_staged_reduce(host, root=0):
+                plot.upload(host)
+                gather.accumulate(plot)
             else:
                 plot.clear()
+        else:
+            gather.accumulate(plot)   # Kahan + clear (gather_unit.rs:49-64, app.rs:147)
+
+    def step():
+        for _ in range(args.launches_per_step):
+            trace.render_fused(scene, plot, paths_per_launch, seed=args.seed, stream=rank, first_path_index=next_path[0])
+            next_path[0] += paths_per_launch
+        gather_step()
 
     def fence():
         trace.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        plot.sync()
+        if gather is not None:
+            gather.sync()
+        D.barrier()
+        trace.sync()
+        plot.sync()
 
-    for i in range(args.warmup):
-        step(i)
-    if world > 1:
-        # Create the communicator and run the reduce once outside the timed region even when the warm-up
-        # steps did not reach a gather (RCCL builds its rings lazily on the first collective).
-        if on_device:
-            dist.reduce(torch.zeros_like(xyz), dst=0, op=dist.ReduceOp.SUM)
-        else:
-            dist.reduce(torch.zeros(xyz.numel(), dtype=torch.float32), dst=0, op=dist.ReduceOp.SUM)
+    for _ in range(args.warmup):
+        step()
+    if args.warmup == 0 and world > 1:
+        gather_step()  # build the communicator's rings outside the timed region (RCCL connects lazily)
     fence()
     p0, s0, ms0 = trace.stats()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
     fence()
     t1 = time.perf_counter()
     p1, s1, ms1 = trace.stats()
-    elapsed = t1 - t0
     rays, paths, kernel_ms = s1 - s0, p1 - p0, ms1 - ms0
-
-    if world > 1:
-        t = torch.tensor([elapsed, float(rays), float(paths), kernel_ms], dtype=torch.float64,
-                         device="cuda" if on_device else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0])
-        total_rays, total_paths = float(t[1]), float(t[2])
-    else:
-        total_rays, total_paths = float(rays), float(paths)
+    elapsed, (total_rays, total_paths) = D.aggregate(t1 - t0, [rays, paths])
 
     if rank == 0:
         f_seg = flops_per_ray(objs)
-        # dominant kernel = rl_trace_kernel; its launches are timed with HIP events on the unit's own stream
-        launch_ms = kernel_ms / args.steps
-        achieved = (rays / args.steps) * f_seg / (launch_ms * 1e-3) / 1e12
+        n_launches = args.steps * args.launches_per_step
+        launch_ms = kernel_ms / n_launches            # HIP events on the trace unit's own stream (rl_api.hip)
+        rays_per_launch = rays / n_launches
+        achieved = rays_per_launch * f_seg / (launch_ms * 1e-3) / 1e12
+        ex = executed_from_profile(R, args.config, args.fetch, rays_per_launch, launch_ms)
+        executed, traffic = ex if isinstance(ex, tuple) else (ex, None)
         out = {
             "metric": "Mrays/sec on built-in scene at %dx%d" % (W, H),
             "value": total_rays / elapsed / 1e6,
@@ -221,35 +325,44 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "built-in %s scene (%d objects), %dx%d, fused trace+plot, %d batches of 524288 paths per step "
-                                   "per GPU, gather every %d steps, RNG stream = rank, primitives in %s"
-                                   % (scene_name if param == 0 else "%s(seeds=%d)" % (scene_name, param), len(objs), W, H,
-                                      args.batches_per_step, args.gather_every, "LDS" if args.fetch == "lds" else "global/scalar cache"),
-                       "config": args.config, "paths_per_step_per_gpu": paths_per_step, "seed": args.seed},
+            "config": {"workload": "built-in %s scene (%d objects), %dx%d, fused trace+plot; one step = %d launches of %d batches of "
+                                   "524288 paths per GPU, then the gather (%s); RNG stream = rank, primitives in %s"
+                                   % (label, len(objs), W, H, args.launches_per_step, args.batches_per_launch,
+                                      "Kahan accumulate + clear" if world == 1 else
+                                      ("RCCL reduce of the XYZ buffers onto rank 0, Kahan accumulate, clear" if comm is not None
+                                       else "host-staged gloo sum onto rank 0, Kahan accumulate, clear"),
+                                      "LDS" if args.fetch == "lds" else "global/scalar cache"),
+                       "config": args.config, "paths_per_step_per_gpu": paths_per_launch * args.launches_per_step,
+                       "paths_per_launch": paths_per_launch, "seed": args.seed, "build_id": R.build_id(),
+                       "dist_backend": None if world == 1 else args.dist_backend},
             "mpaths_per_s": total_paths / elapsed / 1e6,
             "batches_per_s": total_paths / elapsed / BATCH,
             "segments_per_path": total_rays / max(total_paths, 1.0),
+            "timed_region_s": elapsed,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                         "frac_is": "ALGORITHMIC: the reference's linear-scan flops per ray (SURVEY 8d) x rays / kernel time, over the "
+                                    "FP32-vector peak.  The kernel culls most of that scan, so this is a speed-up-over-linear-scan "
+                                    "figure, not a utilisation; `executed` below is what the hardware did",
                          "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
-                         "traffic": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step,
-                         "hbm": {"achieved": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step / (launch_ms * 1e-3) / 1e9,
-                                 "peak": 8000.0, "unit": "GB/s",
-                                 "frac": PROFILED_TRAFFIC_BYTES_PER_PATH * paths_per_step / (launch_ms * 1e-3) / 8e12},
-                         "traffic_note": "bytes per launch, scaled from the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/ "
-                                         "(f32 atomics count as 32-byte writes); algorithmic: 48 B per contributing path",
-                         "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms,
+                         "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flops_per_ray": f_seg,
-                         "valu_busy_profiled": 0.95, "active_lanes_profiled": 0.71,
-                         "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only; "
-                                 "valu_busy / active_lanes from the PMC passes in profiles/r01m_pmc_summary.txt"},
+                         "executed": executed,
+                         "traffic": traffic,
+                         "hbm": ({"achieved": traffic / (launch_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                  "frac": traffic / (launch_ms * 1e-3) / 8e12} if traffic else None),
+                         "traffic_note": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB of the profile named in `executed` "
+                                         "(each f32 atomic is billed as one 32-byte write); algorithmic: 48 B per contributing path; "
+                                         "null when the profile is stale",
+                         "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only"},
         }
+        if world == 1 and not args.no_others:
+            out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, cam, W, H)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        D.shutdown()
 
 
 if __name__ == "__main__":

@@ -1,5 +1,7 @@
 // ffi.rs -- Rust declarations of every entry point of include/robigo_luculenta.h
-// (tests/test_abi.py checks that no function of the header is missing here).
+// (tests/test_abi.py parses both files and compares every function's arity, argument and return types through a
+// C -> Rust type map, and every #[repr(C)] struct's field names, order, types and size with the header and with
+// the ctypes mirror, so a u32 swapped for a u64 fails the test).
 // Documentation artefact: this image has no rustc, so the file is compiled only where cargo exists;
 // INTEGRATION.md explains how the reference's units wrap these handles.
 #![allow(dead_code)]
@@ -17,7 +19,8 @@ use std::os::raw::{c_char, c_double, c_float, c_int};
 }
 #[repr(C)] pub struct RlSceneDesc { pub n_objects: u32, pub objects: *const RlObjectDesc, pub camera: RlCameraDesc }
 
-pub const RL_TASK_MAX_UNITS: usize = 64;
+pub const RL_TASK_MAX_UNITS: usize = 256;
+pub const RL_COMM_ID_BYTES: usize = 128;
 #[repr(C)] #[derive(Copy, Clone)] pub struct RlTask {            // enum Task by value, task_scheduler.rs:26-41
     pub kind: u32,      // 0 Sleep, 1 Trace, 2 Plot, 3 Gather, 4 Tonemap
     pub unit: u32, pub n_units: u32, pub units: [u32; RL_TASK_MAX_UNITS],
@@ -26,20 +29,21 @@ pub const RL_TASK_MAX_UNITS: usize = 64;
     pub width: u32, pub height: u32, pub device: c_int, pub concurrency: u32, pub photons_per_batch: u32,
     pub seed: u64, pub stream: u32, pub builtin_scene: c_int, pub builtin_param: c_int, pub max_batches: u64,
     pub tonemap_interval_ms: i64, pub fused: c_int, pub output_ppm: *const c_char, pub checkpoint: *const c_char,
-    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32,
+    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32, pub first_batch: u64, pub n_devices: u32, pub devices: *const c_int,
 }
 #[repr(C)] #[derive(Copy, Clone, Default)] pub struct RlAppStats {
     pub batches: u64, pub paths: u64, pub segments: u64, pub tasks: [u64; 5], pub seconds: c_double, pub kernel_ms: c_double,
-    pub batches_per_sec_mean: c_float, pub batches_per_sec_stddev: c_float, pub tonemaps: u32,
+    pub batches_per_sec_mean: c_float, pub batches_per_sec_stddev: c_float, pub tonemaps: u32, pub next_batch: u64,
 }
 
 pub enum RlScene {} pub enum RlTraceUnit {} pub enum RlPlotUnit {} pub enum RlGatherUnit {} pub enum RlTonemapUnit {}
-pub enum RlScheduler {}
+pub enum RlScheduler {} pub enum RlComm {}
 
 extern "C" {
     pub fn rl_last_error() -> *const c_char;
     pub fn rl_device_count() -> c_int;
     pub fn rl_version() -> *const c_char;
+    pub fn rl_build_id() -> *const c_char;
     pub fn rl_scene_builtin_desc(which: c_int, param: c_int, objects: *mut RlObjectDesc, cap: u32,
                                  n_objects: *mut u32, camera: *mut RlCameraDesc) -> c_int;
     pub fn rl_scene_desc_save(path: *const c_char, desc: *const RlSceneDesc) -> c_int;
@@ -52,6 +56,7 @@ extern "C" {
     pub fn rl_trace_unit_destroy(u: *mut RlTraceUnit) -> c_int;
     pub fn rl_trace_unit_set_fetch(u: *mut RlTraceUnit, primitive_fetch: c_int) -> c_int;   // 0 LDS, 1 global
     pub fn rl_trace_unit_render(u: *mut RlTraceUnit, scene: *const RlScene, seed: u64, stream: u32, first_path: u64) -> c_int;
+    pub fn rl_trace_unit_render_async(u: *mut RlTraceUnit, scene: *const RlScene, seed: u64, stream: u32, first_path: u64) -> c_int;
     pub fn rl_trace_unit_render_fused(u: *mut RlTraceUnit, scene: *const RlScene, plot: *mut RlPlotUnit,
                                       seed: u64, stream: u32, first_path: u64, n_paths: u64) -> c_int;
     pub fn rl_trace_unit_sync(u: *mut RlTraceUnit) -> c_int;
@@ -62,8 +67,10 @@ extern "C" {
     pub fn rl_plot_unit_destroy(u: *mut RlPlotUnit) -> c_int;
     pub fn rl_plot_unit_plot(u: *mut RlPlotUnit, trace_units: *const *mut RlTraceUnit, n: u32) -> c_int;
     pub fn rl_plot_unit_clear(u: *mut RlPlotUnit) -> c_int;
+    pub fn rl_plot_unit_sync(u: *mut RlPlotUnit) -> c_int;
     pub fn rl_plot_unit_device_buffer(u: *mut RlPlotUnit, device_xyz: *mut *mut f32) -> c_int;
     pub fn rl_plot_unit_download(u: *mut RlPlotUnit, out: *mut RlVector3) -> c_int;
+    pub fn rl_plot_unit_upload(u: *mut RlPlotUnit, input: *const RlVector3) -> c_int;
 
     pub fn rl_gather_unit_create(device: c_int, w: u32, h: u32, out: *mut *mut RlGatherUnit) -> c_int;
     pub fn rl_gather_unit_destroy(u: *mut RlGatherUnit) -> c_int;
@@ -71,6 +78,19 @@ extern "C" {
     pub fn rl_gather_unit_save(u: *mut RlGatherUnit, path: *const c_char) -> c_int;
     pub fn rl_gather_unit_load(u: *mut RlGatherUnit, path: *const c_char) -> c_int;
     pub fn rl_gather_unit_download(u: *mut RlGatherUnit, tristimulus: *mut RlVector3, compensation: *mut RlVector3) -> c_int;
+    pub fn rl_gather_unit_sync(u: *mut RlGatherUnit) -> c_int;
+
+    // The GatherUnit-time exchange between GPUs (RCCL over xGMI, bound at run time).
+    pub fn rl_comm_unique_id(id: *mut u8) -> c_int;                                  // RL_COMM_ID_BYTES bytes
+    pub fn rl_comm_init_rank(id: *const u8, world: c_int, rank: c_int, device: c_int, out: *mut *mut RlComm) -> c_int;
+    pub fn rl_comm_init_all(devices: *const c_int, n: c_int, out: *mut *mut RlComm) -> c_int;
+    pub fn rl_comm_destroy(comm: *mut RlComm) -> c_int;
+    pub fn rl_comm_rank(comm: *const RlComm, rank: *mut c_int, world: *mut c_int) -> c_int;
+    pub fn rl_comm_group_start() -> c_int;
+    pub fn rl_comm_group_end() -> c_int;
+    pub fn rl_plot_unit_reduce(u: *mut RlPlotUnit, comm: *mut RlComm, root: c_int) -> c_int;
+    pub fn rl_plot_unit_add(dst: *mut RlPlotUnit, src: *mut RlPlotUnit) -> c_int;
+    pub fn rl_gather_unit_allreduce(gather: *mut RlGatherUnit, plot: *mut RlPlotUnit, comm: *mut RlComm) -> c_int;
 
     pub fn rl_tonemap_unit_create(device: c_int, w: u32, h: u32, out: *mut *mut RlTonemapUnit) -> c_int;
     pub fn rl_tonemap_unit_destroy(u: *mut RlTonemapUnit) -> c_int;

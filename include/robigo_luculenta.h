@@ -113,11 +113,15 @@ typedef struct RlPlotUnit RlPlotUnit;
 typedef struct RlGatherUnit RlGatherUnit;
 typedef struct RlTonemapUnit RlTonemapUnit;
 typedef struct RlScheduler RlScheduler;
+typedef struct RlComm RlComm;
 
 const char* rl_last_error(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int rl_device_count(void);
 const char* rl_version(void);
+/* 16 hex digits: a hash of the sources this library's device code was compiled from (csrc/Makefile).  Profiles
+ * record it so that counter-derived figures are never quoted for a different build. */
+const char* rl_build_id(void);
 
 /* ---- scene (scene.rs:23-35, app.rs:166-363) ------------------------------------------------ */
 
@@ -151,6 +155,11 @@ int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
  * Complete (device-synchronised) on return. */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
+/* The same without the final wait: the launch is queued on the unit's stream and rl_trace_unit_sync() (or
+ * rl_plot_unit_plot, which orders itself after it on the device) completes it.  Lets one host thread start the
+ * same task on several GPUs before waiting for any of them. */
+int rl_trace_unit_render_async(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
+                               uint64_t first_path_index);
 /* Fused TraceUnit::render + PlotUnit::plot (trace_unit.rs:151-168 + plot_unit.rs:87-95): traces
  * n_paths paths (any count, not limited to the unit's batch size) and splats every non-zero
  * contribution straight into `plot` with f32 atomics; mapped_photons is not written.  After this a
@@ -173,13 +182,22 @@ int rl_trace_unit_stats(RlTraceUnit* unit, uint64_t* paths, uint64_t* segments, 
 int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height, float* external_xyz,
                         RlPlotUnit** out);
 int rl_plot_unit_destroy(RlPlotUnit* unit);
-/* PlotUnit::plot(&mut self, &[MappedPhoton]) for each given trace unit (app.rs:136-141). */
+/* PlotUnit::plot(&mut self, &[MappedPhoton]) for each given trace unit (app.rs:136-141).  ASYNCHRONOUS: the
+ * splat kernels are queued on the plot unit's own (non-blocking) stream, after the trace units' renders; the
+ * trace units may be rendered again at once (their next render waits for this plot on the device).  A later
+ * rl_gather_unit_accumulate / rl_plot_unit_reduce / rl_plot_unit_download of this unit is ordered after it;
+ * anything else that reads the buffer (rl_plot_unit_device_buffer) must call rl_plot_unit_sync first. */
 int rl_plot_unit_plot(RlPlotUnit* unit, RlTraceUnit* const* trace_units, uint32_t n_trace_units);
-/* PlotUnit::clear (plot_unit.rs:98-102). */
+/* PlotUnit::clear (plot_unit.rs:98-102); queued on the unit's stream. */
 int rl_plot_unit_clear(RlPlotUnit* unit);
+/* Blocks until everything queued into this plot unit so far (plots, fused renders, exchanges, clears) is done. */
+int rl_plot_unit_sync(RlPlotUnit* unit);
 /* Device pointer of tristimulus_buffer (plot_unit.rs:35): width*height RlVector3, row-major. */
 int rl_plot_unit_device_buffer(RlPlotUnit* unit, float** device_xyz);
 int rl_plot_unit_download(RlPlotUnit* unit, RlVector3* out);
+/* Overwrites tristimulus_buffer from host memory (after everything queued into the unit): the host-staged form
+ * of the exchange, for ranks that share a GPU, and the tests. */
+int rl_plot_unit_upload(RlPlotUnit* unit, const RlVector3* in);
 
 /* ---- GatherUnit (gather_unit.rs:24-92) ----------------------------------------------------- */
 
@@ -196,6 +214,39 @@ int rl_gather_unit_accumulate(RlGatherUnit* unit, RlPlotUnit* plot);
 int rl_gather_unit_save(RlGatherUnit* unit, const char* path);
 int rl_gather_unit_load(RlGatherUnit* unit, const char* path);
 int rl_gather_unit_download(RlGatherUnit* unit, RlVector3* tristimulus, RlVector3* compensation);
+/* Blocks until every accumulate / tonemap queued on this gather unit is done (they run on its own stream). */
+int rl_gather_unit_sync(RlGatherUnit* unit);
+
+/* ---- the GatherUnit-time exchange between GPUs (no reference counterpart: the reference is one process on
+ * one CPU) ---------------------------------------------------------------------------------------
+ * Samples shard: every GPU renders the full frame with its own RNG stream into its own plot units, and the only
+ * exchange is the element-wise f32 sum of the tristimulus buffers (3*W*H floats) onto rank 0 when a plot unit
+ * is gathered -- one ncclReduce over xGMI -- followed by rank 0's Kahan accumulation (gather_unit.rs:49-64).
+ * RCCL is loaded at run time (dlopen) by the first rl_comm_* call; RL_E_NO_DEVICE if it is absent. */
+#define RL_COMM_ID_BYTES 128
+/* One rank per process (torchrun / MPI style launchers): rank 0 obtains an id, hands the 128 bytes to the other
+ * ranks over any channel, and every rank joins with its own device. */
+int rl_comm_unique_id(uint8_t id[RL_COMM_ID_BYTES]);
+int rl_comm_init_rank(const uint8_t id[RL_COMM_ID_BYTES], int world, int rank, int device, RlComm** out);
+/* One process driving n distinct GPUs: out[i] is rank i on devices[i]. */
+int rl_comm_init_all(const int* devices, int n, RlComm** out);
+int rl_comm_destroy(RlComm* comm);
+int rl_comm_rank(const RlComm* comm, int* rank, int* world);
+/* ncclGroupStart / ncclGroupEnd: a single host thread that issues the collective for several ranks brackets
+ * the calls with these (one thread or process per rank needs neither). */
+int rl_comm_group_start(void);
+int rl_comm_group_end(void);
+/* The exchange: sums this plot unit's tristimulus buffer with those of the other ranks into rank `root`'s
+ * buffer, in place (ncclReduce, f32, sum).  Collective: every rank calls it with its own plot unit of the same
+ * size.  Queued on the plot unit's stream, i.e. after every plot / fused render into the buffer. */
+int rl_plot_unit_reduce(RlPlotUnit* unit, RlComm* comm, int root);
+/* dst += src for two plot units on the SAME device (two RNG streams rendered by one GPU); src is left as it is. */
+int rl_plot_unit_add(RlPlotUnit* dst, RlPlotUnit* src);
+/* Task::Gather on G GPUs in one call per rank: rl_plot_unit_reduce(plot, comm, 0), then on rank 0
+ * rl_gather_unit_accumulate(gather, plot) and on the other ranks rl_plot_unit_clear(plot) (gather may be NULL
+ * there).  For one thread or process per rank; a single thread driving several ranks uses the three calls
+ * itself with the reduces inside rl_comm_group_start/end. */
+int rl_gather_unit_allreduce(RlGatherUnit* gather, RlPlotUnit* plot, RlComm* comm);
 
 /* ---- TonemapUnit (tonemap_unit.rs:21-100, srgb.rs:20-41) ------------------------------------ */
 
@@ -213,7 +264,10 @@ int rl_tonemap_unit_srgb_float(RlTonemapUnit* unit, float* out, float* max_inten
 
 enum RlTaskKind { RL_TASK_SLEEP = 0, RL_TASK_TRACE = 1, RL_TASK_PLOT = 2, RL_TASK_GATHER = 3, RL_TASK_TONEMAP = 4 };
 
-#define RL_TASK_MAX_UNITS 64
+/* Capacity of RlTask::units: 3 * concurrency trace units must fit, so at most 85 worker threads (the reference
+ * uses num_cpus::get(), app.rs:55; a GPU is saturated by 8-16 workers).  rl_scheduler_create and
+ * rl_app_run return RL_E_INVALID with a message naming the limit beyond it. */
+#define RL_TASK_MAX_UNITS 256
 
 /* enum Task by value (task_scheduler.rs:26-41), units named by their ids (trace_unit.rs:59,
  * plot_unit.rs:37).  unit = the trace/plot unit of Trace/Plot; units[] = the trace units of a Plot
@@ -260,6 +314,18 @@ typedef struct RlAppConfig {
     uint32_t sleep_us;           /* how long Task::Sleep waits before the worker asks again.  The reference sleeps
                                     100 ms (app.rs:129) because its tasks take seconds; a task here takes about a
                                     millisecond, so 0 selects 200 us.  100000 restores the reference's value. */
+    uint64_t first_batch;        /* index of the first batch this run renders; batch b is the path indices
+                                    [b * photons_per_batch, (b + 1) * photons_per_batch) of every rank's RNG stream.
+                                    With `resume` the larger of this and the index stored beside the checkpoint
+                                    ("<checkpoint>.next", written with every save) is used, so a resumed run adds new
+                                    samples instead of repeating the old ones.  RlAppStats::next_batch continues a run
+                                    by hand. */
+    uint32_t n_devices;          /* 0 or 1: render on `device`.  G > 1: one process drives G ranks; every scheduler
+                                    unit is one unit per rank, rank r uses RNG stream `stream + r`, and Task::Gather
+                                    sums the ranks' plot buffers onto rank 0 first (rl_plot_unit_reduce over xGMI for
+                                    distinct GPUs, rl_plot_unit_add for ranks that share one) */
+    const int* devices;          /* n_devices device indices, rank 0 first (gather, tonemap and output live there);
+                                    NULL = device, device + 1, ...  A device may be listed more than once. */
 } RlAppConfig;
 
 typedef struct RlAppStats {
@@ -269,11 +335,12 @@ typedef struct RlAppStats {
     double kernel_ms;            /* device time in trace kernels */
     float batches_per_sec_mean, batches_per_sec_stddev; /* task_scheduler.rs:308-325 */
     uint32_t tonemaps;
+    uint64_t next_batch;         /* first_batch of a run that continues this one */
 } RlAppStats;
 
 /* App::new + the worker loops (app.rs:54-111) until max_batches trace tasks are done, gathered and
- * tonemapped once more.  The batches cover the path indices [0, max_batches * photons_per_batch) exactly
- * once (un-fused: trace task number k, in scheduler order, renders batch k; fused: each plot task renders the
+ * tonemapped once more.  The batches cover the path indices [first_batch * photons_per_batch,
+ * (first_batch + max_batches) * photons_per_batch) of every rank's RNG stream exactly once (un-fused: trace task number k, in scheduler order, renders batch k; fused: each plot task renders the
  * batches of its trace units as one launch over the next contiguous range), so the final image does not
  * depend on which worker or unit ran which task.  rgb_out (may be NULL) receives the last RGB8 image. */
 int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);

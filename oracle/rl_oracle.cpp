@@ -796,7 +796,7 @@ void accumulate(RlVector3* acc, RlVector3* comp, const RlVector3* px, uint64_t n
 
 float gamma_correct(float f) {
     if (f <= 0.0031308f) return 12.92f * f;
-    return 1.055f * rl_powf(f, 1.0f / 2.4f) - 0.055f;
+    return 1.055f * rl_powf_full(f, 1.0f / 2.4f) - 0.055f;
 }
 Vector3 srgb_transform(Vector3 cie) {
     float r = 3.2406f * cie.x - 1.5372f * cie.y - 0.4986f * cie.z;
@@ -827,9 +827,9 @@ void tonemap(const RlVector3* tristimuli, uint32_t w, uint32_t h, uint8_t* rgb, 
     float ln_4 = rl_logf(4.0f);
     uint64_t count = (uint64_t)w * h;
     for (uint64_t i = 0; i < count; ++i) {
-        Vector3 cie{rl_logf(tristimuli[i].x / max_intensity + 1.0f) / ln_4,
-                    rl_logf(tristimuli[i].y / max_intensity + 1.0f) / ln_4,
-                    rl_logf(tristimuli[i].z / max_intensity + 1.0f) / ln_4};
+        Vector3 cie{rl_logf_full(tristimuli[i].x / max_intensity + 1.0f) / ln_4,
+                    rl_logf_full(tristimuli[i].y / max_intensity + 1.0f) / ln_4,
+                    rl_logf_full(tristimuli[i].z / max_intensity + 1.0f) / ln_4};
         Vector3 rgbv = srgb_transform(cie);
         float r = clamp01(rgbv.x), g = clamp01(rgbv.y), b = clamp01(rgbv.z);
         if (srgb_float) {
@@ -838,9 +838,9 @@ void tonemap(const RlVector3* tristimuli, uint32_t w, uint32_t h, uint8_t* rgb, 
             srgb_float[3 * i + 2] = b;
         }
         if (rgb) {
-            rgb[3 * i] = (uint8_t)(r * 255.0f);
-            rgb[3 * i + 1] = (uint8_t)(g * 255.0f);
-            rgb[3 * i + 2] = (uint8_t)(b * 255.0f);
+            rgb[3 * i] = rl_to_u8(r * 255.0f);
+            rgb[3 * i + 1] = rl_to_u8(g * 255.0f);
+            rgb[3 * i + 2] = rl_to_u8(b * 255.0f);
         }
     }
 }
@@ -922,7 +922,7 @@ int oracle_intersect_object(void* scene, uint32_t index, const float* origin, co
 int oracle_scene_intersect(void* scene, const float* origin, const float* direction, float* out10) {
     Scene* s = (Scene*)scene;
     Ray ray{Vector3{origin[0], origin[1], origin[2]}, Vector3{direction[0], direction[1], direction[2]}, 0.0f, 1.0f};
-    Intersection i;
+    Intersection i{};
     const Object* o = s->intersect(ray, &i);
     if (!o) return -1;
     float v[10] = {i.position.x, i.position.y, i.position.z, i.normal.x, i.normal.y, i.normal.z,

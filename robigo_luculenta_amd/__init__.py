@@ -29,6 +29,10 @@ def version():
     return lib.rl_version().decode()
 
 
+def build_id():
+    return lib.rl_build_id().decode()
+
+
 def builtin_scene_desc(which=SCENE_DEMO, param=0):
     """Object array (OBJECT_DTYPE) and camera of a built-in scene (app.rs:166-363)."""
     n = C.c_uint32(0)
@@ -114,6 +118,9 @@ class TraceUnit(_Handle):
     def render(self, scene, seed=1, stream=0, first_path_index=0):
         check(lib.rl_trace_unit_render(self._h, scene.handle, seed, stream, first_path_index))
 
+    def render_async(self, scene, seed=1, stream=0, first_path_index=0):
+        check(lib.rl_trace_unit_render_async(self._h, scene.handle, seed, stream, first_path_index))
+
     def render_fused(self, scene, plot_unit, n_paths, seed=1, stream=0, first_path_index=0):
         check(lib.rl_trace_unit_render_fused(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index,
                                              n_paths))
@@ -150,6 +157,17 @@ class PlotUnit(_Handle):
     def clear(self):
         check(lib.rl_plot_unit_clear(self._h))
 
+    def sync(self):
+        check(lib.rl_plot_unit_sync(self._h))
+
+    def reduce(self, comm, root=0):
+        """The GatherUnit-time exchange: sum of every rank's buffer onto `root` (ncclReduce on the unit's stream)."""
+        check(lib.rl_plot_unit_reduce(self._h, comm.handle, root))
+
+    def add(self, other):
+        """self += other (same device)."""
+        check(lib.rl_plot_unit_add(self._h, other.handle))
+
     def device_buffer(self):
         p = C.c_void_p()
         check(lib.rl_plot_unit_device_buffer(self._h, C.byref(p)))
@@ -160,6 +178,10 @@ class PlotUnit(_Handle):
         out = np.zeros((self.height * self.width, 3), dtype=np.float32)
         check(lib.rl_plot_unit_download(self._h, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def upload(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(self.height * self.width, 3)
+        check(lib.rl_plot_unit_upload(self._h, xyz.ctypes.data_as(C.c_void_p)))
 
 
 class GatherUnit(_Handle):
@@ -174,6 +196,13 @@ class GatherUnit(_Handle):
     def accumulate(self, plot_unit):
         """accumulate(&plot.tristimulus_buffer) then plot.clear() (app.rs:143-148)."""
         check(lib.rl_gather_unit_accumulate(self._h, plot_unit.handle))
+
+    def allreduce(self, plot_unit, comm):
+        """Task::Gather across ranks: reduce onto rank 0, which accumulates; the others clear (self may be None there)."""
+        check(lib.rl_gather_unit_allreduce(self._h, plot_unit.handle, comm.handle))
+
+    def sync(self):
+        check(lib.rl_gather_unit_sync(self._h))
 
     def save(self, path="buffer.raw"):
         check(lib.rl_gather_unit_save(self._h, path.encode()))
@@ -194,6 +223,43 @@ class GatherUnit(_Handle):
     @property
     def compensation_buffer(self):
         return self._download()[1]
+
+
+def gather_allreduce(gather, plot_unit, comm):
+    """rl_gather_unit_allreduce: Task::Gather across the ranks of `comm` (gather may be None on ranks other than 0)."""
+    check(lib.rl_gather_unit_allreduce(gather.handle if gather is not None else None, plot_unit.handle, comm.handle))
+
+
+class Comm(_Handle):
+    """One rank of an RCCL communicator (rl_comm_*)."""
+    _destroy = lib.rl_comm_destroy
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib.rl_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, unique_id, world, rank, device=0):
+        super().__init__()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        check(lib.rl_comm_init_rank(buf, world, rank, device, C.byref(self._h)))
+        self.world, self.rank, self.device = world, rank, device
+
+    @classmethod
+    def init_all(cls, devices):
+        """One process, one rank per distinct device."""
+        arr = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        check(lib.rl_comm_init_all(arr, len(devices), out))
+        comms = []
+        for i, d in enumerate(devices):
+            c = cls.__new__(cls)
+            _Handle.__init__(c)
+            c._h = C.c_void_p(out[i])
+            c.world, c.rank, c.device = len(devices), i, d
+            comms.append(c)
+        return comms
 
 
 class TonemapUnit(_Handle):
@@ -274,12 +340,15 @@ class TaskScheduler(_Handle):
 
 def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_batch=NUMBER_OF_PHOTONS, seed=1, stream=0,
             scene=SCENE_DEMO, scene_param=0, tonemap_interval_ms=30000, fused=False, output_ppm=None, checkpoint=None,
-            resume=False, verbose=False, sleep_us=0):
-    """App::new + worker loops (app.rs:54-111) on one GPU until `max_batches` trace tasks are done.
-    Returns (rgb image as (H, W, 3) uint8, stats dict)."""
+            resume=False, verbose=False, sleep_us=0, first_batch=0, devices=None):
+    """App::new + worker loops (app.rs:54-111) until `max_batches` trace tasks are done, on one GPU or, with
+    `devices` = a list of device indices (repeats allowed), on one rank per entry with the plot buffers summed
+    onto rank 0 at every gather.  Returns (rgb image as (H, W, 3) uint8, stats dict)."""
+    dev_arr = (C.c_int * len(devices))(*devices) if devices else None
     cfg = RlAppConfig(width, height, device, concurrency, photons_per_batch, seed, stream, scene, scene_param, max_batches,
                       tonemap_interval_ms, int(fused), output_ppm.encode() if output_ppm else None,
-                      checkpoint.encode() if checkpoint else None, int(resume), int(verbose), sleep_us)
+                      checkpoint.encode() if checkpoint else None, int(resume), int(verbose), sleep_us, first_batch,
+                      len(devices) if devices else 0, dev_arr)
     stats = RlAppStats()
     rgb = np.zeros((height, width, 3), dtype=np.uint8)
     check(lib.rl_app_run(C.byref(cfg), C.byref(stats), rgb.ctypes.data_as(C.c_void_p)))

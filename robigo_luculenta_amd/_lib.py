@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # RL_LIBRARY: a diagnostic build of the same library (e.g. `make -C csrc stats`); never a different implementation.
 LIB_PATH = os.environ.get("RL_LIBRARY") or os.path.join(HERE, "librobigo_luculenta.so")
 
-RL_TASK_MAX_UNITS = 64
+RL_TASK_MAX_UNITS = 256
+RL_COMM_ID_BYTES = 128
 
 
 class RlError(RuntimeError):
@@ -51,13 +52,14 @@ class RlAppConfig(C.Structure):
                 ("photons_per_batch", C.c_uint32), ("seed", C.c_uint64), ("stream", C.c_uint32),
                 ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
                 ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
-                ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32)]
+                ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32),
+                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int))]
 
 
 class RlAppStats(C.Structure):
     _fields_ = [("batches", C.c_uint64), ("paths", C.c_uint64), ("segments", C.c_uint64), ("tasks", C.c_uint64 * 5),
                 ("seconds", C.c_double), ("kernel_ms", C.c_double), ("batches_per_sec_mean", C.c_float),
-                ("batches_per_sec_stddev", C.c_float), ("tonemaps", C.c_uint32)]
+                ("batches_per_sec_stddev", C.c_float), ("tonemaps", C.c_uint32), ("next_batch", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/robigo_luculenta.h declares.
@@ -68,6 +70,7 @@ SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
     "rl_device_count": (_i, []),
     "rl_version": (C.c_char_p, []),
+    "rl_build_id": (C.c_char_p, []),
     "rl_scene_builtin_desc": (_i, [_i, _i, _vp, _u32, C.POINTER(_u32), C.POINTER(RlCameraDesc)]),
     "rl_scene_desc_save": (_i, [C.c_char_p, C.POINTER(RlSceneDesc)]),
     "rl_scene_desc_load": (_i, [C.c_char_p, _vp, _u32, C.POINTER(_u32), C.POINTER(RlCameraDesc)]),
@@ -77,6 +80,7 @@ SIGNATURES = {
     "rl_trace_unit_destroy": (_i, [_vp]),
     "rl_trace_unit_set_fetch": (_i, [_vp, _i]),
     "rl_trace_unit_render": (_i, [_vp, _vp, _u64, _u32, _u64]),
+    "rl_trace_unit_render_async": (_i, [_vp, _vp, _u64, _u32, _u64]),
     "rl_trace_unit_render_fused": (_i, [_vp, _vp, _vp, _u64, _u32, _u64, _u64]),
     "rl_trace_unit_sync": (_i, [_vp]),
     "rl_trace_unit_photons": (_i, [_vp, _vp]),
@@ -85,8 +89,21 @@ SIGNATURES = {
     "rl_plot_unit_destroy": (_i, [_vp]),
     "rl_plot_unit_plot": (_i, [_vp, _pp, _u32]),
     "rl_plot_unit_clear": (_i, [_vp]),
+    "rl_plot_unit_sync": (_i, [_vp]),
+    "rl_plot_unit_reduce": (_i, [_vp, _vp, _i]),
+    "rl_plot_unit_add": (_i, [_vp, _vp]),
+    "rl_gather_unit_allreduce": (_i, [_vp, _vp, _vp]),
+    "rl_comm_unique_id": (_i, [_vp]),
+    "rl_comm_init_rank": (_i, [_vp, _i, _i, _i, _pp]),
+    "rl_comm_init_all": (_i, [C.POINTER(_i), _i, _pp]),
+    "rl_comm_destroy": (_i, [_vp]),
+    "rl_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "rl_comm_group_start": (_i, []),
+    "rl_comm_group_end": (_i, []),
     "rl_plot_unit_device_buffer": (_i, [_vp, _pp]),
     "rl_plot_unit_download": (_i, [_vp, _vp]),
+    "rl_plot_unit_upload": (_i, [_vp, _vp]),
+    "rl_gather_unit_sync": (_i, [_vp]),
     "rl_gather_unit_create": (_i, [_i, _u32, _u32, _pp]),
     "rl_gather_unit_destroy": (_i, [_vp]),
     "rl_gather_unit_accumulate": (_i, [_vp, _vp]),
@@ -107,16 +124,9 @@ SIGNATURES = {
 }
 
 if not os.path.exists(LIB_PATH):
-    # A source checkout without the built library: compile it (hipcc cross-compiles gfx950 without a GPU).
-    # This is still the HIP library -- there is no CPU implementation to fall back to -- and a failed
-    # build is a hard error.
-    import subprocess
-    try:
-        subprocess.run(["make", "-C", os.path.join(HERE, "csrc")], check=True, capture_output=True)
-    except (OSError, subprocess.CalledProcessError) as e:
-        raise ImportError(
-            "robigo_luculenta_amd: %s is missing and could not be built with hipcc --offload-arch=gfx950 (%s); "
-            "run `python -c 'import __graft_entry__ as g; g.build()'`.  There is no CPU fallback." % (LIB_PATH, e))
+    # Nothing is built at import time and there is no CPU implementation to fall back to.
+    raise ImportError("robigo_luculenta_amd: %s is missing; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C robigo_luculenta_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
 
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():

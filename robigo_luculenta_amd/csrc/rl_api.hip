@@ -1,12 +1,21 @@
 // rl_api.hip -- implementation of include/robigo_luculenta.h over the gfx950 kernels.
 //
-// Ordering model: every trace unit and every plot unit owns a blocking HIP stream; gather / tonemap
-// work, clears and all copies run on the device's null stream, which HIP orders against blocking
-// streams, so a (fused) render or a plot followed by a gather needs no explicit event.  The one
-// hazard between two blocking streams -- PlotUnit::plot reading mapped_photons that the trace unit's
-// next render overwrites -- is closed with an event the trace unit's stream waits on.  Trace and plot
-// work of different units therefore overlap on the device.  Entry points never throw.
+// Ordering model: every trace, plot and gather unit owns a NON-blocking HIP stream and nothing relies on the
+// null stream's implicit ordering (RCCL and a host framework's side streams are non-blocking too).  Every
+// hand-over between units is an event:
+//   * a fused render writes the plot unit's buffer from the trace unit's stream: the plot stream waits for it
+//     (so "everything written into this plot unit so far" is always the tail of the plot unit's own stream),
+//     and the render itself waits for the plot unit's last clear;
+//   * PlotUnit::plot reads mapped_photons on the plot stream after the trace unit's render; the trace unit's
+//     next render waits for that plot;
+//   * GatherUnit::accumulate runs on the gather stream after the plot stream's tail, and the plot stream
+//     continues after the clear; tonemap kernels run on the gather stream;
+//   * the GatherUnit-time exchange (rl_plot_unit_reduce, RCCL) is enqueued on the plot stream.
+// Downloads synchronise the stream that produced the data.  Trace and plot work of different units overlap on
+// the device.  Entry points never throw.
 #include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstring>
@@ -14,6 +23,8 @@
 #include <new>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h> // types and prototypes only: the library is bound at run time (rccl_api below)
 
 #include "../../include/robigo_luculenta.h"
 #include "rl_kernels.hip.h"
@@ -70,6 +81,7 @@ struct RlTraceUnit {
     RlMappedPhoton* photons;
     unsigned long long* queue; // 3 counters, see rl_trace_kernel
     hipStream_t stream;
+    hipEvent_t rendered; // recorded after every launch on `stream`
     int fetch;
     int cu_count;
     std::vector<EventPair> pending, pool;
@@ -86,8 +98,10 @@ struct RlPlotUnit {
     float* xyz;
     bool owns;
     RlF4* cie;
-    hipStream_t stream; // rl_plot_kernel launches
+    hipStream_t stream; // rl_plot_kernel launches, clears, the RCCL exchange; its tail = every write into xyz so far
     hipEvent_t plotted; // recorded after the last plot kernel of a PlotUnit::plot call
+    hipEvent_t ready;   // recorded on `stream` when a gather (or a reader on another stream) takes the buffer
+    hipEvent_t cleared; // recorded on the gather stream after accumulate + clear
 };
 
 struct RlGatherUnit {
@@ -95,6 +109,7 @@ struct RlGatherUnit {
     uint32_t width, height;
     float* acc;
     float* comp;
+    hipStream_t stream; // accumulate and tonemap kernels
 };
 
 struct RlTonemapUnit {
@@ -103,6 +118,13 @@ struct RlTonemapUnit {
     uint8_t* rgb;
     float* srgb;
     float* max_intensity;
+    hipStream_t last_stream; // the gather stream the last tonemap ran on (downloads wait for it)
+};
+
+// One rank of an RCCL communicator (rl_comm_*).
+struct RlComm {
+    int device, rank, world;
+    void* nccl; // ncclComm_t
 };
 
 namespace {
@@ -119,9 +141,10 @@ int drain_events(RlTraceUnit* u) {
     return RL_OK;
 }
 
-int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, float* plot, uint64_t seed,
+int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
                  uint32_t stream_id, uint64_t first_path, uint64_t n_paths) {
     if (n_paths == 0) return RL_OK;
+    float* plot = plot_unit ? plot_unit->xyz : nullptr;
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     RlTraceJob job;
     job.width = u->width;
@@ -162,12 +185,15 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         RL_HIP(hipEventCreate(&ep.start));
         RL_HIP(hipEventCreate(&ep.stop));
     }
+    if (plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
                        plot, u->queue);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
+    RL_HIP(hipEventRecord(u->rendered, u->stream));
+    if (plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
     u->pending.push_back(ep);
     u->launches += 1;
     if (u->pending.size() > 512) return drain_events(u);
@@ -215,7 +241,12 @@ int rl_device_count(void) {
     return n;
 }
 
-const char* rl_version(void) { return "robigo-luculenta_amd 0.1 (gfx950)"; }
+const char* rl_version(void) { return "robigo-luculenta_amd 0.2 (gfx950)"; }
+
+#ifndef RL_BUILD_ID
+#define RL_BUILD_ID "unknown"
+#endif
+const char* rl_build_id(void) { return RL_BUILD_ID; }
 
 // ---- scene --------------------------------------------------------------------------------------
 
@@ -355,6 +386,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->photons = nullptr;
     u->queue = nullptr;
     u->stream = nullptr;
+    u->rendered = nullptr;
     u->fetch = RL_FETCH_LDS;
     u->kernel_ms = 0.0;
     u->launches = 0;
@@ -367,7 +399,9 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     if (e == hipSuccess) e = hipMemset(u->photons, 0, (size_t)n_photons * sizeof(RlMappedPhoton)); // MappedPhoton::new
     if (e == hipSuccess) e = hipMalloc((void**)&u->queue, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(u->queue, 0, 3 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipStreamCreate(&u->stream);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->rendered, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipDeviceSynchronize(); // the memsets above ran on the null stream
     if (e != hipSuccess) {
         rl_trace_unit_destroy(u);
         return fail(RL_E_HIP, std::string("trace unit allocation: ") + hipGetErrorString(e));
@@ -393,6 +427,7 @@ int rl_trace_unit_destroy(RlTraceUnit* u) {
         (void)hipEventDestroy(ep.stop);
     }
     if (u->stream) (void)hipStreamDestroy(u->stream);
+    if (u->rendered) (void)hipEventDestroy(u->rendered);
     if (u->photons) (void)hipFree(u->photons);
     if (u->queue) (void)hipFree(u->queue);
     delete u;
@@ -406,11 +441,16 @@ int rl_trace_unit_set_fetch(RlTraceUnit* u, int primitive_fetch) {
     return RL_OK;
 }
 
-int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
+int rl_trace_unit_render_async(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
     if (!u || !scene) return fail(RL_E_INVALID, "null handle");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    if ((rc = launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons)) != RL_OK) return rc;
+    return launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons);
+}
+
+int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
+    int rc = rl_trace_unit_render_async(u, scene, seed, stream, first_path_index);
+    if (rc != RL_OK) return rc;
     RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
@@ -422,7 +462,7 @@ int rl_trace_unit_render_fused(RlTraceUnit* u, const RlScene* scene, RlPlotUnit*
         return fail(RL_E_STATE, "plot unit does not match the trace unit (device or size)");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    return launch_trace(u, scene, nullptr, plot->xyz, seed, stream, first_path_index, n_paths);
+    return launch_trace(u, scene, nullptr, plot, seed, stream, first_path_index, n_paths);
 }
 
 int rl_trace_unit_sync(RlTraceUnit* u) {
@@ -474,7 +514,7 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     u->owns = external_xyz == nullptr;
     u->cie = nullptr;
     u->stream = nullptr;
-    u->plotted = nullptr;
+    u->plotted = u->ready = u->cleared = nullptr;
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     hipError_t e = hipSuccess;
     if (u->owns) {
@@ -483,8 +523,11 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     }
     if (e == hipSuccess) e = hipMalloc((void**)&u->cie, sizeof RL_CIE1931_XYZ0);
     if (e == hipSuccess) e = hipMemcpy(u->cie, RL_CIE1931_XYZ0, sizeof RL_CIE1931_XYZ0, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreate(&u->stream);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->plotted, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->cleared, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipDeviceSynchronize(); // the synchronous memsets / copies above ran on the null stream
     if (e != hipSuccess) {
         rl_plot_unit_destroy(u);
         return fail(RL_E_HIP, std::string("plot unit allocation: ") + hipGetErrorString(e));
@@ -501,6 +544,8 @@ int rl_plot_unit_destroy(RlPlotUnit* u) {
         (void)hipStreamDestroy(u->stream);
     }
     if (u->plotted) (void)hipEventDestroy(u->plotted);
+    if (u->ready) (void)hipEventDestroy(u->ready);
+    if (u->cleared) (void)hipEventDestroy(u->cleared);
     if (u->owns && u->xyz) (void)hipFree(u->xyz);
     if (u->cie) (void)hipFree(u->cie);
     delete u;
@@ -517,6 +562,7 @@ int rl_plot_unit_plot(RlPlotUnit* u, RlTraceUnit* const* trace_units, uint32_t n
     for (uint32_t k = 0; k < n_trace_units; ++k) {           // app.rs:138-140
         RlTraceUnit* t = trace_units[k];
         if (!t || t->device != u->device) return fail(RL_E_STATE, "trace unit missing or on another device");
+        RL_HIP(hipStreamWaitEvent(u->stream, t->rendered, 0)); // mapped_photons complete (a no-op after a synchronous render)
         hipLaunchKernelGGL(rl_plot_kernel, dim3(grid_for(t->n_photons, cus)), dim3(RL_BLOCK), 0, u->stream, t->photons,
                            t->n_photons, u->cie, u->width, u->height, aspect, u->xyz);
         RL_HIP(hipGetLastError());
@@ -534,7 +580,16 @@ int rl_plot_unit_clear(RlPlotUnit* u) {
     if (!u) return fail(RL_E_INVALID, "null plot unit");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    RL_HIP(hipMemsetAsync(u->xyz, 0, (size_t)u->width * u->height * 3 * sizeof(float), 0));
+    RL_HIP(hipMemsetAsync(u->xyz, 0, (size_t)u->width * u->height * 3 * sizeof(float), u->stream));
+    RL_HIP(hipEventRecord(u->cleared, u->stream)); // later fused renders wait for this
+    return RL_OK;
+}
+
+int rl_plot_unit_sync(RlPlotUnit* u) {
+    if (!u) return fail(RL_E_INVALID, "null plot unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
 
@@ -544,10 +599,21 @@ int rl_plot_unit_device_buffer(RlPlotUnit* u, float** device_xyz) {
     return RL_OK;
 }
 
+int rl_plot_unit_upload(RlPlotUnit* u, const RlVector3* in) {
+    if (!u || !in) return fail(RL_E_INVALID, "null argument");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
+    RL_HIP(hipMemcpy(u->xyz, in, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyHostToDevice));
+    RL_HIP(hipDeviceSynchronize());
+    return RL_OK;
+}
+
 int rl_plot_unit_download(RlPlotUnit* u, RlVector3* out) {
     if (!u || !out) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
     RL_HIP(hipMemcpy(out, u->xyz, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyDeviceToHost));
     return RL_OK;
 }
@@ -566,11 +632,14 @@ int rl_gather_unit_create(int device, uint32_t width, uint32_t height, RlGatherU
     u->width = width;
     u->height = height;
     u->acc = u->comp = nullptr;
+    u->stream = nullptr;
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     hipError_t e = hipMalloc((void**)&u->acc, bytes);
     if (e == hipSuccess) e = hipMemset(u->acc, 0, bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&u->comp, bytes);
     if (e == hipSuccess) e = hipMemset(u->comp, 0, bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         rl_gather_unit_destroy(u);
         return fail(RL_E_HIP, std::string("gather unit allocation: ") + hipGetErrorString(e));
@@ -582,6 +651,10 @@ int rl_gather_unit_create(int device, uint32_t width, uint32_t height, RlGatherU
 int rl_gather_unit_destroy(RlGatherUnit* u) {
     if (!u) return RL_OK;
     (void)hipSetDevice(u->device);
+    if (u->stream) {
+        (void)hipStreamSynchronize(u->stream);
+        (void)hipStreamDestroy(u->stream);
+    }
     if (u->acc) (void)hipFree(u->acc);
     if (u->comp) (void)hipFree(u->comp);
     delete u;
@@ -597,9 +670,21 @@ int rl_gather_unit_accumulate(RlGatherUnit* u, RlPlotUnit* plot) {
     int cus = 256;
     if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
     const uint64_t n_floats = (uint64_t)u->width * u->height * 3;
-    hipLaunchKernelGGL(rl_gather_kernel, dim3(grid_for(n_floats / 4 + 1, cus)), dim3(RL_BLOCK), 0, 0, u->acc, u->comp, plot->xyz,
-                       n_floats);
+    RL_HIP(hipEventRecord(plot->ready, plot->stream));        // everything plotted / splatted / reduced into the buffer so far
+    RL_HIP(hipStreamWaitEvent(u->stream, plot->ready, 0));
+    hipLaunchKernelGGL(rl_gather_kernel, dim3(grid_for(n_floats / 4 + 1, cus)), dim3(RL_BLOCK), 0, u->stream, u->acc, u->comp,
+                       plot->xyz, n_floats);
     RL_HIP(hipGetLastError());
+    RL_HIP(hipEventRecord(plot->cleared, u->stream));         // the kernel also cleared the plot buffer (app.rs:147)
+    RL_HIP(hipStreamWaitEvent(plot->stream, plot->cleared, 0));
+    return RL_OK;
+}
+
+int rl_gather_unit_sync(RlGatherUnit* u) {
+    if (!u) return fail(RL_E_INVALID, "null gather unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
 
@@ -608,6 +693,7 @@ int rl_gather_unit_download(RlGatherUnit* u, RlVector3* tristimulus, RlVector3* 
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
     const size_t bytes = (size_t)u->width * u->height * sizeof(RlVector3);
+    RL_HIP(hipStreamSynchronize(u->stream));
     if (tristimulus) RL_HIP(hipMemcpy(tristimulus, u->acc, bytes, hipMemcpyDeviceToHost));
     if (compensation) RL_HIP(hipMemcpy(compensation, u->comp, bytes, hipMemcpyDeviceToHost));
     return RL_OK;
@@ -642,8 +728,9 @@ int rl_gather_unit_load(RlGatherUnit* u, const char* path) {
     }
     (void)std::fread(host.data(), 1, 2 * n * sizeof(RlVector3), f);
     std::fclose(f);
-    RL_HIP(hipMemcpy(u->acc, host.data(), n * sizeof(RlVector3), hipMemcpyHostToDevice));
+    RL_HIP(hipMemcpy(u->acc, host.data(), n * sizeof(RlVector3), hipMemcpyHostToDevice)); // the download above drained u->stream
     RL_HIP(hipMemcpy(u->comp, host.data() + n, n * sizeof(RlVector3), hipMemcpyHostToDevice));
+    RL_HIP(hipDeviceSynchronize());
     return RL_OK;
 }
 
@@ -663,6 +750,7 @@ int rl_tonemap_unit_create(int device, uint32_t width, uint32_t height, RlTonema
     u->rgb = nullptr;
     u->srgb = nullptr;
     u->max_intensity = nullptr;
+    u->last_stream = nullptr;
     const size_t n = (size_t)width * height * 3;
     hipError_t e = hipMalloc((void**)&u->rgb, n);
     if (e == hipSuccess) e = hipMemset(u->rgb, 0, n);
@@ -670,6 +758,7 @@ int rl_tonemap_unit_create(int device, uint32_t width, uint32_t height, RlTonema
     if (e == hipSuccess) e = hipMemset(u->srgb, 0, n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&u->max_intensity, sizeof(float));
     if (e == hipSuccess) e = hipMemset(u->max_intensity, 0, sizeof(float));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         rl_tonemap_unit_destroy(u);
         return fail(RL_E_HIP, std::string("tonemap unit allocation: ") + hipGetErrorString(e));
@@ -697,11 +786,13 @@ int rl_tonemap_unit_tonemap(RlTonemapUnit* u, RlGatherUnit* gather) {
     int cus = 256;
     if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
     const uint32_t n_pixels = u->width * u->height;
-    hipLaunchKernelGGL(rl_exposure_kernel, dim3(1), dim3(64), 0, 0, gather->acc, n_pixels, (float)n_pixels, u->max_intensity);
+    hipLaunchKernelGGL(rl_exposure_kernel, dim3(1), dim3(64), 0, gather->stream, gather->acc, n_pixels, (float)n_pixels,
+                       u->max_intensity);
     RL_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rl_tonemap_kernel, dim3(grid_for(n_pixels, cus)), dim3(RL_BLOCK), 0, 0, gather->acc, n_pixels,
+    hipLaunchKernelGGL(rl_tonemap_kernel, dim3(grid_for(n_pixels, cus)), dim3(RL_BLOCK), 0, gather->stream, gather->acc, n_pixels,
                        u->max_intensity, u->rgb, u->srgb);
     RL_HIP(hipGetLastError());
+    u->last_stream = gather->stream;
     return RL_OK;
 }
 
@@ -709,6 +800,7 @@ int rl_tonemap_unit_rgb(RlTonemapUnit* u, uint8_t* out) {
     if (!u || !out) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if (u->last_stream) RL_HIP(hipStreamSynchronize(u->last_stream));
     RL_HIP(hipMemcpy(out, u->rgb, (size_t)u->width * u->height * 3, hipMemcpyDeviceToHost));
     return RL_OK;
 }
@@ -717,9 +809,211 @@ int rl_tonemap_unit_srgb_float(RlTonemapUnit* u, float* out, float* max_intensit
     if (!u) return fail(RL_E_INVALID, "null tonemap unit");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if (u->last_stream) RL_HIP(hipStreamSynchronize(u->last_stream));
     if (out) RL_HIP(hipMemcpy(out, u->srgb, (size_t)u->width * u->height * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (max_intensity) RL_HIP(hipMemcpy(max_intensity, u->max_intensity, sizeof(float), hipMemcpyDeviceToHost));
     return RL_OK;
+}
+
+// ---- GatherUnit-time exchange across GPUs (gather_unit.rs:49-64 with the plot buffers of G GPUs) ----
+
+namespace {
+
+// RCCL is bound with dlopen at the first rl_comm_* call, not at link time: the library then loads on hosts
+// without RCCL (single-GPU use), and inside a process that already holds an RCCL (PyTorch ships its own copy
+// under the same SONAME) the one copy in the process is shared instead of a second one being mapped.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // The RCCL that belongs to the HIP runtime THIS library is running on: the one installed beside the
+        // libamdhip64 that hipGetDeviceCount resolves to.  A process may hold two ROCm stacks (PyTorch bundles its own HIP,
+        // HSA and RCCL under the same SONAMEs); picking RCCL by bare name can pair it with a second, uninitialised
+        // HSA runtime ("no ROCm-capable device is detected").  Bare names are the fall-back.
+        std::vector<std::string> names;
+        Dl_info info;
+        if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (const std::string& n : names) {
+            api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) {
+            api.error = std::string("RCCL (librccl.so.1) could not be loaded: ") + dlerror();
+            return;
+        }
+#define RL_BIND(NAME)                                                                  \
+    api.NAME = (decltype(api.NAME))dlsym(api.handle, "nccl" #NAME);                     \
+    if (!api.NAME && api.error.empty()) api.error = "RCCL symbol nccl" #NAME " missing";
+        RL_BIND(GetUniqueId) RL_BIND(CommInitRank) RL_BIND(CommInitAll) RL_BIND(CommDestroy) RL_BIND(Reduce)
+        RL_BIND(GroupStart) RL_BIND(GroupEnd) RL_BIND(GetErrorString)
+#undef RL_BIND
+    });
+    return &api;
+}
+
+#define RL_NCCL(api, call)                                                                                  \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) return fail(RL_E_HIP, std::string(#call) + ": " + (api)->GetErrorString(r_)); \
+    } while (0)
+
+__global__ __launch_bounds__(RL_BLOCK) void rl_add_kernel(float* __restrict__ dst, const float* __restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * RL_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * RL_BLOCK) dst[i] = dst[i] + src[i];
+}
+
+} // namespace
+
+int rl_comm_unique_id(uint8_t id[RL_COMM_ID_BYTES]) {
+    if (!id) return fail(RL_E_INVALID, "null id");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    static_assert(sizeof(ncclUniqueId) == RL_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    RL_NCCL(api, api->GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return RL_OK;
+}
+
+int rl_comm_init_rank(const uint8_t id[RL_COMM_ID_BYTES], int world, int rank, int device, RlComm** out) {
+    if (!out) return fail(RL_E_INVALID, "null output handle");
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(RL_E_INVALID, "bad communicator arguments");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    ncclComm_t c = nullptr;
+    RL_NCCL(api, api->CommInitRank(&c, world, u, rank));
+    RlComm* r = new (std::nothrow) RlComm();
+    if (!r) return fail(RL_E_INVALID, "out of host memory");
+    r->device = device;
+    r->rank = rank;
+    r->world = world;
+    r->nccl = c;
+    *out = r;
+    return RL_OK;
+}
+
+int rl_comm_init_all(const int* devices, int n, RlComm** out) {
+    if (!devices || !out || n < 1) return fail(RL_E_INVALID, "bad communicator arguments");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) return fail(RL_E_INVALID, "an RCCL communicator needs distinct devices (one rank per GPU)");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    int rc = use_device(devices[0]);
+    if (rc != RL_OK) return rc;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    RL_NCCL(api, api->CommInitAll(comms.data(), n, devices));
+    for (int i = 0; i < n; ++i) {
+        RlComm* r = new (std::nothrow) RlComm();
+        if (!r) return fail(RL_E_INVALID, "out of host memory");
+        r->device = devices[i];
+        r->rank = i;
+        r->world = n;
+        r->nccl = comms[i];
+        out[i] = r;
+    }
+    return RL_OK;
+}
+
+int rl_comm_destroy(RlComm* c) {
+    if (!c) return RL_OK;
+    RcclApi* api = rccl_api();
+    (void)hipSetDevice(c->device);
+    if (api->CommDestroy && c->nccl) (void)api->CommDestroy((ncclComm_t)c->nccl);
+    delete c;
+    return RL_OK;
+}
+
+int rl_comm_rank(const RlComm* c, int* rank, int* world) {
+    if (!c) return fail(RL_E_INVALID, "null communicator");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return RL_OK;
+}
+
+int rl_comm_group_start(void) {
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    RL_NCCL(api, api->GroupStart());
+    return RL_OK;
+}
+
+int rl_comm_group_end(void) {
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    RL_NCCL(api, api->GroupEnd());
+    return RL_OK;
+}
+
+int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
+    if (!u || !comm) return fail(RL_E_INVALID, "null handle");
+    if (comm->device != u->device) return fail(RL_E_STATE, "communicator rank and plot unit live on different devices");
+    if (root < 0 || root >= comm->world) return fail(RL_E_INVALID, "root out of range");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    const size_t count = (size_t)u->width * u->height * 3;
+    // In place on the root; on the plot unit's stream, i.e. after every plot / fused splat into this buffer.
+    RL_NCCL(api, api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream));
+    return RL_OK;
+}
+
+int rl_plot_unit_add(RlPlotUnit* dst, RlPlotUnit* src) {
+    if (!dst || !src) return fail(RL_E_INVALID, "null handle");
+    if (dst == src) return fail(RL_E_INVALID, "a plot unit cannot be added to itself");
+    if (dst->device != src->device || dst->width != src->width || dst->height != src->height)
+        return fail(RL_E_STATE, "plot units do not match (device or size)");
+    int rc = use_device(dst->device);
+    if (rc != RL_OK) return rc;
+    int cus = 256;
+    if ((rc = cu_count_of(dst->device, &cus)) != RL_OK) return rc;
+    const uint64_t n = (uint64_t)dst->width * dst->height * 3;
+    RL_HIP(hipEventRecord(src->ready, src->stream));
+    RL_HIP(hipStreamWaitEvent(dst->stream, src->ready, 0));
+    hipLaunchKernelGGL(rl_add_kernel, dim3(grid_for(n, cus)), dim3(RL_BLOCK), 0, dst->stream, dst->xyz, src->xyz, n);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipEventRecord(dst->plotted, dst->stream));
+    RL_HIP(hipStreamWaitEvent(src->stream, dst->plotted, 0)); // src may be cleared or splatted into only after it was read
+    return RL_OK;
+}
+
+int rl_gather_unit_allreduce(RlGatherUnit* gather, RlPlotUnit* plot, RlComm* comm) {
+    if (!plot || !comm) return fail(RL_E_INVALID, "null handle");
+    if (comm->rank == 0 && !gather) return fail(RL_E_INVALID, "rank 0 accumulates: it needs the gather unit");
+    int rc = rl_plot_unit_reduce(plot, comm, 0);
+    if (rc != RL_OK) return rc;
+    if (comm->rank == 0) return rl_gather_unit_accumulate(gather, plot); // Kahan + clear (gather_unit.rs:49-64, app.rs:147)
+    return rl_plot_unit_clear(plot);
 }
 
 // ---- device-side math probe (tests) -------------------------------------------------------------

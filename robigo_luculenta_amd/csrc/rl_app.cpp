@@ -7,6 +7,14 @@
 // checkpoint / image file names; and forced by the time scale (a task takes a millisecond, not
 // seconds): Task::Sleep waits 200 us instead of 100 ms (app.rs:129; RlAppConfig::sleep_us), and in
 // fused mode a Plot task renders the batches of its trace units as one launch.
+//
+// Several GPUs in one process (RlAppConfig::n_devices > 1): every unit of the scheduler is a LOGICAL unit
+// with one physical unit per rank (= per GPU, or per RNG stream when a device is listed twice).  A Trace or
+// Plot task runs on all ranks at once -- same batch indices, RNG stream = stream + rank, so the ranks' samples
+// are disjoint -- and a Gather task first sums the ranks' plot buffers onto rank 0 (ranks sharing a device by
+// a device-local add, distinct devices by one grouped ncclReduce over xGMI: rl_plot_unit_reduce) and then
+// Kahan-accumulates on rank 0 (gather_unit.rs:49-64).  One scheduler, the reference's protocol unchanged, and
+// the collective is in lockstep by construction because one worker thread issues it for all ranks.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -23,15 +31,25 @@ void rl_internal_set_last_error(const std::string& msg); // rl_api.hip
 
 namespace {
 
+struct Rank { // one GPU (or one RNG stream of a GPU that is listed twice)
+    int device = 0;
+    int leader = 0;            // first rank on the same device
+    RlScene* scene = nullptr;
+    RlComm* comm = nullptr;    // set on device leaders when there is more than one distinct device
+    std::vector<RlTraceUnit*> trace_units;
+    std::vector<RlPlotUnit*> plot_units;
+};
+
 struct AppState {
     const RlAppConfig* cfg;
     RlScheduler* scheduler = nullptr;
-    RlScene* scene = nullptr;
-    std::vector<RlTraceUnit*> trace_units;
-    std::vector<RlPlotUnit*> plot_units;
-    RlGatherUnit* gather = nullptr;
-    RlTonemapUnit* tonemap = nullptr;
+    std::vector<Rank> ranks;
+    bool use_rccl = false;     // more than one distinct device
+    RlGatherUnit* gather = nullptr;   // on rank 0's device
+    RlTonemapUnit* tonemap = nullptr; // on rank 0's device
+    uint64_t first_batch = 0;
     std::mutex lock;                       // Arc<Mutex<TaskScheduler>>, app.rs:57
+    std::mutex lock_counters;              // traces_issued, read by save_checkpoint outside `lock`
     std::chrono::steady_clock::time_point t0;
     uint64_t traces_issued = 0;            // under `lock`
     std::atomic<uint64_t> fused_next_path{0}; // fused mode: next unrendered path index
@@ -137,6 +155,29 @@ int write_image(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
     return write_ppm(path, rgb, w, h);
 }
 
+// buffer.raw (gather_unit.rs:68-79) plus a sidecar "<checkpoint>.next" holding the index of the first batch a
+// resumed run must render.  The reference needs no such thing -- every restart draws fresh numbers from its
+// OS-seeded generator -- but here a path is a pure function of (seed, stream, path index), so a resumed run that
+// started at batch 0 again would add the very same samples twice: brighter, not less noisy.  The index written
+// is one past the highest batch handed out so far; batches still in flight when the file is written are
+// skipped on resume, never repeated.
+std::string sidecar_path(const char* checkpoint) { return std::string(checkpoint) + ".next"; }
+
+int save_checkpoint(AppState& a) {
+    int rc = rl_gather_unit_save(a.gather, a.cfg->checkpoint);
+    if (rc != RL_OK) return rc;
+    uint64_t next;
+    {
+        std::lock_guard<std::mutex> guard(a.lock_counters);
+        next = a.first_batch + a.traces_issued;
+    }
+    FILE* f = std::fopen(sidecar_path(a.cfg->checkpoint).c_str(), "w");
+    if (!f) return RL_E_IO;
+    std::fprintf(f, "next_batch %llu\nphotons_per_batch %u\nseed %llu\nstream %u\nranks %zu\n", (unsigned long long)next, a.photons,
+                 (unsigned long long)a.cfg->seed, a.cfg->stream, a.ranks.size());
+    return std::fclose(f) == 0 ? RL_OK : RL_E_IO;
+}
+
 // App::execute_task (app.rs:113-126)
 void execute_task(AppState& a, const RlTask& task) {
     const RlAppConfig& c = *a.cfg;
@@ -145,15 +186,22 @@ void execute_task(AppState& a, const RlTask& task) {
     case RL_TASK_SLEEP: // app.rs:128-130, at the time scale of GPU tasks (RlAppConfig::sleep_us)
         std::this_thread::sleep_for(std::chrono::microseconds(c.sleep_us ? c.sleep_us : 200u));
         break;
-    case RL_TASK_TRACE: // app.rs:132-134
-        if (!c.fused) rc = rl_trace_unit_render(a.trace_units[task.unit], a.scene, c.seed, c.stream, a.trace_first_path[task.unit]);
+    case RL_TASK_TRACE: // app.rs:132-134, on every rank: launch everywhere, then wait
+        if (!c.fused) {
+            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r)
+                rc = rl_trace_unit_render_async(a.ranks[r].trace_units[task.unit], a.ranks[r].scene, c.seed, c.stream + (uint32_t)r,
+                                                a.trace_first_path[task.unit]);
+            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
+        }
         // fused: the photons are produced when the unit is plotted (the target buffer is known then)
         break;
     case RL_TASK_PLOT: // app.rs:136-141
         if (!c.fused) {
-            std::vector<RlTraceUnit*> units;
-            for (uint32_t i = 0; i < task.n_units; ++i) units.push_back(a.trace_units[task.units[i]]);
-            rc = rl_plot_unit_plot(a.plot_units[task.unit], units.data(), (uint32_t)units.size());
+            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
+                std::vector<RlTraceUnit*> units;
+                for (uint32_t i = 0; i < task.n_units; ++i) units.push_back(a.ranks[r].trace_units[task.units[i]]);
+                rc = rl_plot_unit_plot(a.ranks[r].plot_units[task.unit], units.data(), (uint32_t)units.size());
+            }
         } else {
             // The batches of all the trace units of this task go out as ONE launch over one contiguous
             // range of path indices: a 524,288-path launch of its own would keep an MI355X busy for 0.15 ms
@@ -163,20 +211,40 @@ void execute_task(AppState& a, const RlTask& task) {
             if (task.n_units != 0) {
                 const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
                 const uint64_t first = a.fused_next_path.fetch_add(n);
-                RlTraceUnit* u = a.trace_units[task.units[0]];
-                rc = rl_trace_unit_render_fused(u, a.scene, a.plot_units[task.unit], c.seed, c.stream, first, n);
-                if (rc == RL_OK) rc = rl_trace_unit_sync(u);
+                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r)
+                    rc = rl_trace_unit_render_fused(a.ranks[r].trace_units[task.units[0]], a.ranks[r].scene, a.ranks[r].plot_units[task.unit],
+                                                    c.seed, c.stream + (uint32_t)r, first, n);
+                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
             }
         }
         break;
     case RL_TASK_GATHER: // app.rs:143-152 (save moved to tonemap time)
-        for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) rc = rl_gather_unit_accumulate(a.gather, a.plot_units[task.units[i]]);
+        for (uint32_t i = 0; i < task.n_units && rc == RL_OK; ++i) {
+            const uint32_t j = task.units[i];
+            // ranks that share a GPU: a device-local sum onto the device's first rank
+            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r)
+                if (a.ranks[r].leader != (int)r) {
+                    rc = rl_plot_unit_add(a.ranks[a.ranks[r].leader].plot_units[j], a.ranks[r].plot_units[j]);
+                    if (rc == RL_OK) rc = rl_plot_unit_clear(a.ranks[r].plot_units[j]);
+                }
+            // distinct GPUs: one grouped ncclReduce onto rank 0 over xGMI
+            if (a.use_rccl && rc == RL_OK) {
+                rc = rl_comm_group_start();
+                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r)
+                    if (a.ranks[r].comm) rc = rl_plot_unit_reduce(a.ranks[r].plot_units[j], a.ranks[r].comm, 0);
+                const int end_rc = rl_comm_group_end();
+                if (rc == RL_OK) rc = end_rc;
+                for (size_t r = 1; r < a.ranks.size() && rc == RL_OK; ++r)
+                    if (a.ranks[r].comm) rc = rl_plot_unit_clear(a.ranks[r].plot_units[j]);
+            }
+            if (rc == RL_OK) rc = rl_gather_unit_accumulate(a.gather, a.ranks[0].plot_units[j]); // Kahan + clear
+        }
         break;
     case RL_TASK_TONEMAP: // app.rs:154-164
         rc = rl_tonemap_unit_tonemap(a.tonemap, a.gather);
         if (rc == RL_OK) rc = rl_tonemap_unit_rgb(a.tonemap, a.rgb.data());
         if (rc == RL_OK && c.output_ppm) rc = write_image(c.output_ppm, a.rgb.data(), c.width, c.height);
-        if (rc == RL_OK && c.checkpoint) rc = rl_gather_unit_save(a.gather, c.checkpoint);
+        if (rc == RL_OK && c.checkpoint) rc = save_checkpoint(a);
         if (rc == RL_OK && c.verbose && c.output_ppm) std::printf("wrote image to %s\n", c.output_ppm);
         break;
     default: break;
@@ -225,7 +293,8 @@ void worker(AppState* ap) {
                     // the reference's protocol, so leave it out of circulation and stop this worker.
                     return;
                 }
-                a.trace_first_path[next.unit] = a.traces_issued * (uint64_t)a.photons;
+                a.trace_first_path[next.unit] = (a.first_batch + a.traces_issued) * (uint64_t)a.photons;
+                std::lock_guard<std::mutex> counters(a.lock_counters);
                 a.traces_issued += 1;
             }
             if (next.kind == RL_TASK_TONEMAP) a.tonemaps += 1;
@@ -249,13 +318,45 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
         rl_internal_set_last_error("rl_app_run: null config, zero-sized image or zero workers");
         return RL_E_INVALID;
     }
+    if (config->concurrency * 3 > RL_TASK_MAX_UNITS) {
+        rl_internal_set_last_error("rl_app_run: concurrency " + std::to_string(config->concurrency) + " needs " +
+                                   std::to_string(config->concurrency * 3) + " trace units, more than RL_TASK_MAX_UNITS = " +
+                                   std::to_string(RL_TASK_MAX_UNITS) + " (at most " + std::to_string(RL_TASK_MAX_UNITS / 3) + " workers)");
+        return RL_E_INVALID;
+    }
     AppState a;
     a.cfg = config;
+    a.t0 = std::chrono::steady_clock::now(); // also the origin of `seconds` when set-up fails
     a.photons = config->photons_per_batch ? config->photons_per_batch : 1024u * 512u;
     a.rgb.assign((size_t)config->width * config->height * 3, 0);
     const uint32_t n_trace = config->concurrency * 3;                          // task_scheduler.rs:95
     const uint32_t n_plot = config->concurrency / 2 > 1 ? config->concurrency / 2 : 1; // :96
     int rc = rl_scheduler_create(config->concurrency, config->tonemap_interval_ms, &a.scheduler);
+    if (rc != RL_OK) rl_internal_set_last_error("rl_app_run: rl_scheduler_create failed");
+
+    // The ranks: one per listed device (a device may be listed more than once: several RNG streams on one GPU).
+    const uint32_t n_ranks = config->n_devices > 1 ? config->n_devices : 1;
+    a.ranks.resize(n_ranks);
+    std::vector<int> distinct;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        Rank& k = a.ranks[r];
+        k.device = config->n_devices > 1 ? (config->devices ? config->devices[r] : config->device + (int)r) : config->device;
+        k.leader = (int)r;
+        for (uint32_t q = 0; q < r; ++q)
+            if (a.ranks[q].device == k.device) {
+                k.leader = a.ranks[q].leader;
+                break;
+            }
+        if (k.leader == (int)r) distinct.push_back(k.device);
+    }
+    a.use_rccl = distinct.size() > 1;
+    if (rc == RL_OK && a.use_rccl) {
+        std::vector<RlComm*> comms(distinct.size(), nullptr);
+        rc = rl_comm_init_all(distinct.data(), (int)distinct.size(), comms.data()); // rank 0's device is distinct[0] = comm rank 0
+        size_t next = 0;
+        for (uint32_t r = 0; r < n_ranks; ++r)
+            if (a.ranks[r].leader == (int)r) a.ranks[r].comm = comms[next++];
+    }
 
     std::vector<RlObjectDesc> objects;
     RlCameraDesc camera;
@@ -265,32 +366,42 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
         objects.resize(n_objects);
         rc = rl_scene_builtin_desc(config->builtin_scene, config->builtin_param, objects.data(), n_objects, &n_objects, &camera);
     }
-    if (rc == RL_OK) {
+    for (uint32_t r = 0; r < n_ranks && rc == RL_OK; ++r) {
+        Rank& k = a.ranks[r];
         RlSceneDesc desc;
         desc.n_objects = n_objects;
         desc.objects = objects.data();
         desc.camera = camera;
-        rc = rl_scene_create(&desc, config->device, &a.scene); // Arc::new(App::set_up_scene()), app.rs:63
+        rc = rl_scene_create(&desc, k.device, &k.scene); // Arc::new(App::set_up_scene()), app.rs:63: one copy per rank
+        for (uint32_t i = 0; i < n_trace && rc == RL_OK; ++i) {
+            RlTraceUnit* u = nullptr;
+            rc = rl_trace_unit_create(k.device, i, config->width, config->height, a.photons, &u);
+            if (u) k.trace_units.push_back(u);
+        }
+        for (uint32_t i = 0; i < n_plot && rc == RL_OK; ++i) {
+            RlPlotUnit* u = nullptr;
+            rc = rl_plot_unit_create(k.device, i, config->width, config->height, nullptr, &u);
+            if (u) k.plot_units.push_back(u);
+        }
     }
-    for (uint32_t i = 0; i < n_trace && rc == RL_OK; ++i) {
-        RlTraceUnit* u = nullptr;
-        rc = rl_trace_unit_create(config->device, i, config->width, config->height, a.photons, &u);
-        if (u) a.trace_units.push_back(u);
-    }
-    for (uint32_t i = 0; i < n_plot && rc == RL_OK; ++i) {
-        RlPlotUnit* u = nullptr;
-        rc = rl_plot_unit_create(config->device, i, config->width, config->height, nullptr, &u);
-        if (u) a.plot_units.push_back(u);
-    }
-    if (rc == RL_OK) rc = rl_gather_unit_create(config->device, config->width, config->height, &a.gather);
-    if (rc == RL_OK) rc = rl_tonemap_unit_create(config->device, config->width, config->height, &a.tonemap);
+    const int root_device = a.ranks[0].device;
+    if (rc == RL_OK) rc = rl_gather_unit_create(root_device, config->width, config->height, &a.gather);
+    if (rc == RL_OK) rc = rl_tonemap_unit_create(root_device, config->width, config->height, &a.tonemap);
+    a.first_batch = config->first_batch;
     if (rc == RL_OK && config->resume && config->checkpoint) {
         FILE* f = std::fopen(config->checkpoint, "rb"); // a missing file is not an error (gather_unit.rs:82)
         if (f) {
             std::fclose(f);
             rc = rl_gather_unit_load(a.gather, config->checkpoint);
+            // Continue where the checkpointed run stopped handing out batches (see save_checkpoint).
+            if (FILE* g = std::fopen(sidecar_path(config->checkpoint).c_str(), "r")) {
+                unsigned long long next = 0;
+                if (std::fscanf(g, "next_batch %llu", &next) == 1 && next > a.first_batch) a.first_batch = next;
+                std::fclose(g);
+            }
         }
     }
+    a.fused_next_path = a.first_batch * (uint64_t)a.photons;
     a.trace_first_path.assign(n_trace, 0);
 
     if (rc == RL_OK) {
@@ -340,28 +451,34 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->batches = a.traces_issued;
+        stats->next_batch = a.first_batch + a.traces_issued;
         stats->seconds = seconds;
         stats->tonemaps = a.tonemaps;
         for (int k = 0; k < 5; ++k) stats->tasks[k] = a.tasks[k];
-        for (RlTraceUnit* u : a.trace_units) {
-            uint64_t p = 0, s = 0;
-            double ms = 0;
-            if (rl_trace_unit_stats(u, &p, &s, &ms) == RL_OK) {
-                stats->paths += p;
-                stats->segments += s;
-                stats->kernel_ms += ms;
+        for (Rank& k : a.ranks)
+            for (RlTraceUnit* u : k.trace_units) {
+                uint64_t p = 0, s = 0;
+                double ms = 0;
+                if (rl_trace_unit_stats(u, &p, &s, &ms) == RL_OK) {
+                    stats->paths += p;
+                    stats->segments += s;
+                    stats->kernel_ms += ms;
+                }
             }
-        }
         if (a.scheduler) rl_scheduler_performance(a.scheduler, &stats->batches_per_sec_mean, &stats->batches_per_sec_stddev);
     }
     if (rgb_out && rc == RL_OK) std::memcpy(rgb_out, a.rgb.data(), a.rgb.size());
     std::string message = a.error_message;
-    for (RlTraceUnit* u : a.trace_units) rl_trace_unit_destroy(u);
-    for (RlPlotUnit* u : a.plot_units) rl_plot_unit_destroy(u);
+    if (rc != RL_OK && message.empty()) message = rl_last_error(); // a set-up call on this thread failed
+    for (Rank& k : a.ranks) {
+        for (RlTraceUnit* u : k.trace_units) rl_trace_unit_destroy(u);
+        for (RlPlotUnit* u : k.plot_units) rl_plot_unit_destroy(u);
+        rl_scene_destroy(k.scene);
+    }
     rl_gather_unit_destroy(a.gather);
     rl_tonemap_unit_destroy(a.tonemap);
-    rl_scene_destroy(a.scene);
+    for (Rank& k : a.ranks) rl_comm_destroy(k.comm);
     rl_scheduler_destroy(a.scheduler);
-    if (rc != RL_OK && !message.empty()) rl_internal_set_last_error(message); // the failing call ran on a worker thread
+    if (rc != RL_OK && !message.empty()) rl_internal_set_last_error(message); // the failing call may have run on a worker thread
     return rc;
 }

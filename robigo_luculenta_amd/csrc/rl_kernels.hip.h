@@ -63,13 +63,12 @@ __device__ __forceinline__ unsigned long long rl_cycles() {
     return t;
 }
 #define RL_T0(V) const unsigned long long V = rl_cycles()
-#define RL_T1(K, V) tacc[(K) - RL_ST_T_TOTAL] += rl_cycles() - (V)
-#define RL_TACC_PARAM , unsigned long long* tacc
-#define RL_TACC_ARG , tacc
-#define RL_STAT(K, V)                                                                                \
-    do {                                                                                             \
-        if ((threadIdx.x & 63u) == 0) atomicAdd(&rl_stat_counters[K], (unsigned long long)(V));      \
-    } while (0)
+#define RL_T1(K, V) st[K] += rl_cycles() - (V)
+#define RL_TACC_PARAM , unsigned long long* st
+#define RL_TACC_ARG , st
+// Counters live in (wave-uniform) registers of the wave and reach memory once, when the wave ends: one atomic
+// per event from 4096 waves onto two dozen addresses made the diagnostic build 20x slower than the product.
+#define RL_STAT(K, V) st[K] += (unsigned long long)(V)
 #else
 #define RL_STAT(K, V) do { } while (0)
 #define RL_T0(V) do { } while (0)
@@ -470,8 +469,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     bool ended_on_emitter = false;
     uint32_t emit_obj = 0;
 #ifdef RL_STATS
-    unsigned long long tacc[RL_ST_COUNT - RL_ST_T_TOTAL];
-    for (int k = 0; k < RL_ST_COUNT - RL_ST_T_TOTAL; ++k) tacc[k] = 0;
+    unsigned long long st[RL_ST_COUNT];
+    for (int k = 0; k < RL_ST_COUNT; ++k) st[k] = 0;
 #endif
     RL_T0(t_total);
 
@@ -651,7 +650,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     if (FUSED && e_tail != e_head) process_emitted(e_tail - e_head);
     RL_T1(RL_ST_T_TOTAL, t_total);
 #ifdef RL_STATS
-    for (int k = 0; k < RL_ST_COUNT - RL_ST_T_TOTAL; ++k) RL_STAT(RL_ST_T_TOTAL + k, tacc[k]);
+    if (lane == 0)
+        for (int k = 0; k < RL_ST_COUNT; ++k) atomicAdd(&rl_stat_counters[k], st[k]);
 #endif
     // One atomic per wave for the counters.
     uint32_t s = segments, d = paths_done;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(64) void rl_exposure_kernel(const float* __restrict
 // srgb.rs:20-26
 __device__ __forceinline__ float rl_gamma_correct(float f) {
     if (f <= 0.0031308f) return 12.92f * f;
-    return 1.055f * rl_powf(f, 1.0f / 2.4f) - 0.055f;
+    return 1.055f * rl_powf_full(f, 1.0f / 2.4f) - 0.055f;
 }
 __device__ __forceinline__ float rl_clamp01(float x) { // tonemap_unit.rs:34-38
     if (x < 0.0f) return 0.0f;
@@ -774,18 +774,18 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __res
     const float max_intensity = max_intensity_ptr[0];
     const float ln_4 = rl_logf(4.0f);
     for (uint32_t i = blockIdx.x * RL_BLOCK + threadIdx.x; i < n_pixels; i += gridDim.x * RL_BLOCK) {
-        const float cx = rl_logf(xyz[3ull * i + 0] / max_intensity + 1.0f) / ln_4;
-        const float cy = rl_logf(xyz[3ull * i + 1] / max_intensity + 1.0f) / ln_4;
-        const float cz = rl_logf(xyz[3ull * i + 2] / max_intensity + 1.0f) / ln_4;
+        const float cx = rl_logf_full(xyz[3ull * i + 0] / max_intensity + 1.0f) / ln_4;
+        const float cy = rl_logf_full(xyz[3ull * i + 1] / max_intensity + 1.0f) / ln_4;
+        const float cz = rl_logf_full(xyz[3ull * i + 2] / max_intensity + 1.0f) / ln_4;
         const float r = rl_clamp01(rl_gamma_correct(3.2406f * cx - 1.5372f * cy - 0.4986f * cz));
         const float g = rl_clamp01(rl_gamma_correct(-0.9689f * cx + 1.8758f * cy + 0.0415f * cz));
         const float b = rl_clamp01(rl_gamma_correct(0.0557f * cx - 0.2040f * cy + 1.0570f * cz));
         srgb[3ull * i + 0] = r;
         srgb[3ull * i + 1] = g;
         srgb[3ull * i + 2] = b;
-        rgb[3ull * i + 0] = (uint8_t)(r * 255.0f);
-        rgb[3ull * i + 1] = (uint8_t)(g * 255.0f);
-        rgb[3ull * i + 2] = (uint8_t)(b * 255.0f);
+        rgb[3ull * i + 0] = rl_to_u8(r * 255.0f);
+        rgb[3ull * i + 1] = rl_to_u8(g * 255.0f);
+        rgb[3ull * i + 2] = rl_to_u8(b * 255.0f);
     }
 }
 

@@ -8,7 +8,11 @@
 #include <deque>
 #include <new>
 
+#include <string>
+
 #include "../../include/robigo_luculenta.h"
+
+void rl_internal_set_last_error(const std::string& msg); // rl_api.hip
 
 struct RlScheduler {
     uint32_t traces_completed;                                           // task_scheduler.rs:51
@@ -98,9 +102,17 @@ int rl_scheduler_create(uint32_t concurrency, int64_t tonemap_interval_ms, RlSch
     *out = nullptr;
     const uint32_t n_trace_units = concurrency * 3;                      // task_scheduler.rs:95
     const uint32_t n_plot_units = std::max<uint32_t>(1, concurrency / 2); // :96
-    if (concurrency == 0 || n_trace_units > RL_TASK_MAX_UNITS || n_plot_units > RL_TASK_MAX_UNITS) return RL_E_INVALID;
+    if (concurrency == 0 || n_trace_units > RL_TASK_MAX_UNITS || n_plot_units > RL_TASK_MAX_UNITS) {
+        rl_internal_set_last_error("rl_scheduler_create: concurrency must be between 1 and " + std::to_string(RL_TASK_MAX_UNITS / 3) +
+                                   " (3 * concurrency trace units have to fit RlTask::units, RL_TASK_MAX_UNITS = " +
+                                   std::to_string(RL_TASK_MAX_UNITS) + ")");
+        return RL_E_INVALID;
+    }
     RlScheduler* s = new (std::nothrow) RlScheduler();
-    if (!s) return RL_E_INVALID;
+    if (!s) {
+        rl_internal_set_last_error("rl_scheduler_create: out of host memory");
+        return RL_E_INVALID;
+    }
     s->traces_completed = 0;
     s->number_of_trace_units = n_trace_units;
     for (uint32_t i = 0; i < n_trace_units; ++i) s->available_trace_units.push_back(i);
@@ -120,8 +132,14 @@ int rl_scheduler_destroy(RlScheduler* s) {
 }
 
 int rl_scheduler_get_new_task(RlScheduler* s, const RlTask* completed, int64_t now_ms, RlTask* next) {
-    if (!s || !completed || !next) return RL_E_INVALID;
-    if (completed->n_units > RL_TASK_MAX_UNITS) return RL_E_INVALID;
+    if (!s || !completed || !next) {
+        rl_internal_set_last_error("rl_scheduler_get_new_task: null argument");
+        return RL_E_INVALID;
+    }
+    if (completed->n_units > RL_TASK_MAX_UNITS) {
+        rl_internal_set_last_error("rl_scheduler_get_new_task: completed task lists more than RL_TASK_MAX_UNITS units");
+        return RL_E_INVALID;
+    }
     complete_task(s, completed, now_ms); // task_scheduler.rs:129
     next->kind = RL_TASK_SLEEP;
     next->unit = 0;
@@ -158,7 +176,10 @@ int rl_scheduler_get_new_task(RlScheduler* s, const RlTask* completed, int64_t n
 }
 
 int rl_scheduler_performance(RlScheduler* s, float* mean_out, float* stddev_out) { // task_scheduler.rs:317-325
-    if (!s) return RL_E_INVALID;
+    if (!s) {
+        rl_internal_set_last_error("rl_scheduler_performance: null scheduler");
+        return RL_E_INVALID;
+    }
     const float n = (float)s->performance.size();
     float sum = 0.0f, sq = 0.0f;
     for (float x : s->performance) sum += x;

@@ -1,0 +1,218 @@
+"""GPU tests of what round 2 added around the trace kernel: explicit stream ordering, the GatherUnit-time exchange
+(RCCL through the C ABI, device-local add, host-staged), the multi-rank App, resume without repeated samples, the
+degenerate-image tonemap, and bench.py's N > 1 branch on one GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def R():
+    import robigo_luculenta_amd as R
+    assert R.device_count() > 0
+    return R
+
+
+def _ocam(cam):
+    return O.RlCameraDesc.from_buffer_copy(bytes(cam))
+
+
+def test_black_image_tonemaps_to_black_like_the_reference(R):
+    """max_intensity = 0 makes every pixel 0/0 = NaN; the reference carries NaN through ln, the matrix, the gamma curve
+    and the clamp to `NaN as u8` = 0 (tonemap_unit.rs:73-100).  ADVICE r01: the kernel used to write 255."""
+    W, H = 64, 36
+    g, tm = R.GatherUnit(W, H), R.TonemapUnit(W, H)
+    tm.tonemap(g)
+    want_rgb, want_srgb, want_mx = O.tonemap(np.zeros((W * H, 3), np.float32), W, H)
+    assert not want_rgb.any() and want_mx == 0.0
+    assert tm.rgb_buffer.tobytes() == want_rgb.tobytes()
+    srgb, mx = tm.srgb_float()
+    assert mx == 0.0 and np.isnan(srgb).all() and np.isnan(want_srgb).all()
+    # an image with a single lit pixel: finite exposure, everything else exactly as the oracle
+    xyz = np.zeros((W * H, 3), np.float32)
+    xyz[5] = (0.3, 0.5, 0.2)
+    p = R.PlotUnit(0, W, H)
+    p.upload(xyz)
+    g.accumulate(p)
+    tm.tonemap(g)
+    want_rgb, want_srgb, _ = O.tonemap(xyz, W, H)
+    assert tm.rgb_buffer.tobytes() == want_rgb.tobytes() and tm.srgb_float()[0].tobytes() == want_srgb.tobytes()
+
+
+def test_plot_unit_add_upload_and_async_ordering(R):
+    W, H, N = 96, 54, 1 << 14
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    t0, t1 = R.TraceUnit(0, W, H, n_photons=N), R.TraceUnit(1, W, H, n_photons=N)
+    a, b = R.PlotUnit(0, W, H), R.PlotUnit(1, W, H)
+    # asynchronous renders on two units, plotted without a host-side wait in between: the device-side events order it
+    t0.render_async(scene, seed=4, stream=0, first_path_index=0)
+    t1.render_async(scene, seed=4, stream=1, first_path_index=0)
+    a.plot([t0])
+    b.plot([t1])
+    want = [O.plot(W, H, oscene.render(W, H, 4, s, 0, N, threads=4)[0]) for s in (0, 1)]
+    xa, xb = a.tristimulus_buffer, b.tristimulus_buffer
+    assert np.allclose(xa, want[0], rtol=2e-5, atol=1e-7) and np.allclose(xb, want[1], rtol=2e-5, atol=1e-7)
+    a.add(b)                                            # rl_plot_unit_add: dst += src on one device
+    assert a.tristimulus_buffer.tobytes() == (xa + xb).tobytes() and b.tristimulus_buffer.tobytes() == xb.tobytes()
+    # unit re-use right after an asynchronous plot: the next render must wait for the plot that reads mapped_photons
+    t0.render(scene, seed=4, stream=0, first_path_index=N)
+    assert t0.mapped_photons.tobytes() == oscene.render(W, H, 4, 0, N, N, threads=4)[0].tobytes()
+    with pytest.raises(R.RlError):
+        a.add(a)
+
+
+def test_rccl_exchange_through_the_c_abi_with_one_rank(R):
+    """The library's own RCCL binding (dlopen, ncclCommInitAll / ncclCommInitRank, ncclReduce on the plot stream) on
+    the one GPU this box has: with a single rank the reduce leaves the buffer as it is, and rl_gather_unit_allreduce
+    equals accumulate.  (Two ranks need two GPUs; ranks sharing a GPU use rl_plot_unit_add, tested above.)"""
+    W, H, N = 64, 36, 1 << 13
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    (comm,) = R.Comm.init_all([0])
+    assert (comm.rank, comm.world) == (0, 1)
+    t, p, g, g2 = R.TraceUnit(0, W, H, n_photons=N), R.PlotUnit(0, W, H), R.GatherUnit(W, H), R.GatherUnit(W, H)
+    t.render_fused(scene, p, N, seed=2, stream=0, first_path_index=0)
+    t.sync()
+    before = p.tristimulus_buffer
+    assert before.any()
+    p.reduce(comm, root=0)
+    assert p.tristimulus_buffer.tobytes() == before.tobytes()
+    R.gather_allreduce(g, p, comm)
+    assert g.tristimulus_buffer.tobytes() == before.tobytes() and not p.tristimulus_buffer.any()
+    # multi-process style: id from rank 0, rl_comm_init_rank
+    comm2 = R.Comm(R.Comm.unique_id(), 1, 0, 0)
+    p.upload(before)
+    R.gather_allreduce(g2, p, comm2)
+    assert g2.tristimulus_buffer.tobytes() == before.tobytes()
+    with pytest.raises(R.RlError):
+        R.Comm.init_all([0, 0])       # RCCL admits one rank per device
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_app_with_two_ranks_on_one_gpu_renders_the_sum_of_two_streams(R, fused):
+    """rl_app_run with devices = [0, 0]: every scheduler unit is one unit per rank, rank r renders RNG stream r, and
+    Task::Gather sums the ranks' plot buffers onto rank 0 before the Kahan accumulation -- the single-process form of
+    the 8-GPU layout (distinct devices take the ncclReduce branch of the same code)."""
+    W, H, n, batches = 96, 54, 1 << 14, 10
+    rgb, st = R.app_run(W, H, batches, concurrency=3, photons_per_batch=n, seed=5, fused=fused, devices=[0, 0])
+    assert st["batches"] == batches and st["paths"] == 2 * batches * n
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    xyz = np.zeros((W * H, 3), np.float32)
+    segs = 0
+    for stream in (0, 1):
+        photons, s = oscene.render(W, H, 5, stream, 0, batches * n, threads=8)
+        O.plot(W, H, photons, xyz)
+        segs += s
+    assert st["segments"] == segs
+    want_rgb, _, _ = O.tonemap(xyz, W, H)
+    assert np.abs(rgb.reshape(-1, 3).astype(int) - want_rgb.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_resumed_run_adds_new_samples(R, fused, tmp_path):
+    """resume used to start at path 0 again and add the same samples twice.  Two runs of N batches, the
+    second resumed from the first's checkpoint, must equal one run of 2N batches."""
+    W, H, n, N = 80, 45, 1 << 13, 6
+    raw = str(tmp_path / "buffer.raw")
+    kw = dict(concurrency=2, photons_per_batch=n, seed=9, fused=fused)
+    _, st1 = R.app_run(W, H, N, checkpoint=raw, **kw)
+    assert st1["next_batch"] == N and open(raw + ".next").read().startswith("next_batch %d\n" % N)
+    rgb2, st2 = R.app_run(W, H, N, checkpoint=raw, resume=True, **kw)
+    assert st2["batches"] == N and st2["next_batch"] == 2 * N
+    rgb_once, st_once = R.app_run(W, H, 2 * N, **kw)
+    assert st1["segments"] + st2["segments"] == st_once["segments"]      # the same 2N batches, none twice
+    assert np.abs(rgb2.astype(int) - rgb_once.astype(int)).max() <= 1
+    # the old behaviour, for contrast: N batches rendered twice is a different (brighter-noise) image
+    rgb_twice, _ = R.app_run(W, H, N, first_batch=0, **kw)
+    assert st_once["segments"] != 2 * st1["segments"]
+    # first_batch by hand continues a run without a sidecar
+    _, st3 = R.app_run(W, H, 2, first_batch=st2["next_batch"], **kw)
+    assert st3["next_batch"] == 2 * N + 2
+    assert rgb_twice.shape == rgb_once.shape
+
+
+def test_scheduler_limit_is_reported_with_a_message(R):
+    with pytest.raises(R.RlError) as e:
+        R.app_run(64, 36, 1, concurrency=86)
+    assert "RL_TASK_MAX_UNITS" in str(e.value)
+    rgb, st = R.app_run(64, 36, 4, concurrency=24, photons_per_batch=4096)   # > 21 workers used to be refused
+    assert st["batches"] == 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import torch  # noqa: F401
+    import robigo_luculenta_amd as R
+    from robigo_luculenta_amd import distributed as D
+    D.init_control_plane(rank, world)
+    W, H, n, launches = 96, 54, 1 << 15, 3
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam, device=0)
+    trace, plot = R.TraceUnit(rank, W, H, n_photons=64, device=0), R.PlotUnit(rank, W, H, device=0)
+    gather = R.GatherUnit(W, H, device=0) if rank == 0 else None
+    for k in range(launches):                       # bench.py's step with the host-staged exchange
+        trace.render_fused(scene, plot, n, seed=1, stream=rank, first_path_index=k * n)
+        host = plot.tristimulus_buffer
+        if D.host_staged_reduce(host, root=0):
+            plot.upload(host)
+            gather.accumulate(plot)
+        else:
+            plot.clear()
+    if rank == 0:
+        tm = R.TonemapUnit(W, H)
+        tm.tonemap(gather)
+        np.save(os.path.join(out_dir, "srgb.npy"), tm.srgb_float()[0])
+    D.shutdown()
+
+
+def test_two_ranks_on_one_gpu_reproduce_the_two_stream_image(R, tmp_path):
+    """Two processes share GPU 0, render RNG streams 0 and 1 and exchange at every gather exactly as
+    `bench.py --gpus 2 --dist-backend gloo` does; the image must be the oracle's two-stream image within 1e-3 sRGB."""
+    import torch.multiprocessing as mp
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "srgb.npy")
+    W, H, n, launches = 96, 54, 1 << 15, 3
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    acc, comp = np.zeros((W * H, 3), np.float32), np.zeros((W * H, 3), np.float32)
+    for k in range(launches):
+        xyz = np.zeros((W * H, 3), np.float32)
+        for stream in (0, 1):
+            O.plot(W, H, oscene.render(W, H, 1, stream, k * n, n, threads=8)[0], xyz)
+        O.accumulate(acc, comp, xyz)
+    _, want, _ = O.tonemap(acc, W, H)
+    assert np.abs(got - want).max() <= 1e-3
+
+
+def test_bench_runs_its_own_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher spawns its ranks; with --dist-backend gloo they share GPU 0."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--launches-per-step", "1", "--batches-per-launch", "4", "--config", "demo-720p"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run(cmd, env=env, capture_output=True, timeout=600, check=True).stdout.decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["dist_backend"] == "gloo"
+    assert line["mpaths_per_s"] > 0 and abs(line["segments_per_path"] - 3.54) < 0.1
+    assert line["value"] > 0 and "cpu_baseline" not in line
