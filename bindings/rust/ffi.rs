@@ -29,7 +29,7 @@ pub const RL_COMM_ID_BYTES: usize = 128;
     pub width: u32, pub height: u32, pub device: c_int, pub concurrency: u32, pub photons_per_batch: u32,
     pub seed: u64, pub stream: u32, pub builtin_scene: c_int, pub builtin_param: c_int, pub max_batches: u64,
     pub tonemap_interval_ms: i64, pub fused: c_int, pub output_ppm: *const c_char, pub checkpoint: *const c_char,
-    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32, pub first_batch: u64, pub n_devices: u32, pub devices: *const c_int,
+    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32, pub first_batch: u64, pub n_devices: u32, pub queued_trace: c_int, pub devices: *const c_int,
 }
 #[repr(C)] #[derive(Copy, Clone, Default)] pub struct RlAppStats {
     pub batches: u64, pub paths: u64, pub segments: u64, pub tasks: [u64; 5], pub seconds: c_double, pub kernel_ms: c_double,
@@ -106,6 +106,7 @@ extern "C" {
     pub fn rl_scheduler_performance(s: *mut RlScheduler, mean: *mut f32, stddev: *mut f32) -> c_int;
     pub fn rl_app_run(config: *const RlAppConfig, stats: *mut RlAppStats, rgb_out: *mut u8) -> c_int;
 
+    pub fn rl_debug_batch_histogram(device: c_int, out: *mut u64) -> c_int;
     pub fn rl_debug_math_probe(device: c_int, func: c_int, x: *const f32, y: *mut f32, n: u32) -> c_int;
 }
 

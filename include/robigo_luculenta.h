@@ -152,7 +152,11 @@ int rl_trace_unit_destroy(RlTraceUnit* unit);
 int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
 /* TraceUnit::render(&mut self, &Scene) (trace_unit.rs:151-168): fills the unit's mapped_photons.
  * Photon i of this call is path (first_path_index + i) of RNG stream `stream` under `seed`.
- * Complete (device-synchronised) on return. */
+ * Complete (device-synchronised) on return.  Calls made at the same time from several threads (the reference's
+ * workers, app.rs:92-134) on units of one device with the same scene, seed, stream, image and batch size are
+ * merged into ONE kernel launch behind this call -- the results are bit-identical to separate launches; the
+ * device-time and path counters of a merged launch are accounted to the unit whose thread issued it
+ * (rl_trace_unit_stats sums over the units of a run stay exact). */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
 /* The same without the final wait: the launch is queued on the unit's stream and rl_trace_unit_sync() (or
@@ -324,6 +328,10 @@ typedef struct RlAppConfig {
                                     unit is one unit per rank, rank r uses RNG stream `stream + r`, and Task::Gather
                                     sums the ranks' plot buffers onto rank 0 first (rl_plot_unit_reduce over xGMI for
                                     distinct GPUs, rl_plot_unit_add for ranks that share one) */
+    int queued_trace;            /* un-fused mode.  0 (default): a Trace task is the blocking rl_trace_unit_render, like a
+                                    reference worker -- concurrent workers' calls are merged into one launch (see there);
+                                    non-zero: the launch is queued and the worker moves on (the device orders Plot after
+                                    Trace by itself); measured slower at the reference's task size */
     const int* devices;          /* n_devices device indices, rank 0 first (gather, tonemap and output live there);
                                     NULL = device, device + 1, ...  A device may be listed more than once. */
 } RlAppConfig;
@@ -353,6 +361,9 @@ int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
  * 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette decision (trace_unit.rs:122-125) for the triples
  * (x[i], x[m+i], x[2m+i]) = (rand, continue_chance, intensity), i < m = n / 3, result 1 or 0 in y[i]. */
 int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
+/* Concurrent rl_trace_unit_render calls are merged into one launch (see rl_trace_unit_render).  out[k], k = 1..64:
+ * launches on `device` that carried k calls since the library was loaded (65 counters, out[0] unused). */
+int rl_debug_batch_histogram(int device, uint64_t* out);
 
 #ifdef __cplusplus
 }

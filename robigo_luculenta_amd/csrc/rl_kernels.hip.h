@@ -40,8 +40,17 @@ struct RlTraceJob {
     float aspect_ratio;
     uint32_t stream;
     uint64_t seed;
+    uint64_t first_path;     // single job: path index of offset 0
+    uint64_t n_paths;        // all jobs together
+    uint32_t n_jobs;         // > 1: a merged launch of several TraceUnit::render calls (rl_api.hip's batcher)
+    uint32_t paths_per_job;  // a multiple of RL_CHUNK, so the 64 offsets of a stash refill belong to one job
+};
+
+// One TraceUnit::render of a merged launch: offsets [k * paths_per_job, (k + 1) * paths_per_job) of the launch are
+// path indices first_path .. of this job and fill this unit's mapped_photons.
+struct RlJobEntry {
+    RlMappedPhoton* photons;
     uint64_t first_path;
-    uint64_t n_paths;
 };
 
 // Diagnostic build only (make stats): wave-level event counters of the trace kernel, read back by
@@ -132,7 +141,7 @@ struct RlWaveScratch {
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
     // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior, then
-    // the path's offset in the launch (lo, hi; ~0 = no path).  Refilled with all 64 lanes busy.
+    // the path's index in its RNG stream (lo, hi; both ~0 = no path).  Refilled with all 64 lanes busy.
     float stash[10][64];
     uint32_t stash_off[2][64];
     // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
@@ -415,7 +424,8 @@ template <bool STAGE_LDS, bool FUSED>
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                                   RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                                   float* __restrict__ plot,
-                                                                  unsigned long long* __restrict__ queue) {
+                                                                  unsigned long long* __restrict__ queue,
+                                                                  const RlJobEntry* __restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
     const RlF4* base = scene;
     RlWaveScratch* scratch = (RlWaveScratch*)smem;
@@ -453,7 +463,10 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     uint32_t stash_head = 0, stash_count = 0;   // wave-uniform
     bool drained = false;                       // wave-uniform: the queue has no more paths for this wave
     bool active = false;
-    uint64_t my_offset = 0;
+    uint64_t my_path = 0;  // the path's index in its RNG stream
+    uint32_t my_job = 0;   // merged launches: which job the path belongs to
+    uint32_t stash_job = 0;               // wave-uniform: the job of the stash's current content
+    uint64_t stash_first = job.first_path; // wave-uniform: path index of launch offset 0 as seen by that job
     RlPath p;
     p.origin = rl_f3(0.0f, 0.0f, 0.0f); // a lane without a path scans a null ray; rl_scan_wave's idle_bit mutes it
     p.direction = rl_f3(0.0f, 0.0f, 0.0f);
@@ -523,12 +536,18 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     chunk_end = chunk_next + chunk;
                 }
                 RL_STAT(RL_ST_REFILLS, 1);
+                if (!FUSED && job.n_jobs > 1) { // all 64 offsets of a refill lie in one job (paths_per_job % RL_CHUNK == 0)
+                    const uint32_t j = (uint32_t)(chunk_next / job.paths_per_job);
+                    stash_job = j < job.n_jobs ? j : job.n_jobs - 1u;
+                    stash_first = jobs[stash_job].first_path - (uint64_t)stash_job * job.paths_per_job;
+                }
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
                 const bool valid = offset < job.n_paths;
+                const uint64_t path_index = stash_first + offset;
                 RlPath fresh = p;
                 RL_T0(t_cam);
-                if (valid) rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, job.first_path + offset, &fresh);
+                if (valid) rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, path_index, &fresh);
                 RL_T1(RL_ST_T_CAMERA, t_cam);
                 rl_wave_sync();
                 stash[0 * 64 + lane] = fresh.origin.x;
@@ -541,8 +560,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 stash[7 * 64 + lane] = fresh.sx;
                 stash[8 * 64 + lane] = fresh.sy;
                 stash[9 * 64 + lane] = fresh.ior;
-                stash_off[lane] = valid ? (uint32_t)offset : 0xffffffffu;
-                stash_off[64 + lane] = valid ? (uint32_t)(offset >> 32) : 0xffffffffu;
+                stash_off[lane] = valid ? (uint32_t)path_index : 0xffffffffu;       // (~0, ~0) marks "no path"; a real
+                stash_off[64 + lane] = valid ? (uint32_t)(path_index >> 32) : 0xffffffffu; // index never gets there
                 rl_wave_sync();
                 stash_head = 0;
                 stash_count = 64;
@@ -554,7 +573,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 const uint32_t slot = stash_head + rank;
                 const uint32_t lo = stash_off[slot], hi = stash_off[64 + slot];
                 if ((lo & hi) != 0xffffffffu) {
-                    my_offset = ((uint64_t)hi << 32) | lo;
+                    my_path = ((uint64_t)hi << 32) | lo;
+                    my_job = stash_job;
                     p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
                     p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
                     p.wavelength = stash[6 * 64 + slot];
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             segments += 1;
             float value;
             uint32_t emitter = 0;
-            const int status = rl_bounce(sv, job.seed, job.stream, job.first_path + my_offset, &p, hit, &value, &emitter);
+            const int status = rl_bounce(sv, job.seed, job.stream, my_path, &p, hit, &value, &emitter);
             if (status != RL_PATH_CONTINUES) {
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
@@ -616,7 +636,12 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     ph.y = p.sy;
                     ph.probability = value;
                     ph.wavelength = p.wavelength;
-                    photons[my_offset] = ph;
+                    if (job.n_jobs > 1) {
+                        const RlJobEntry e = jobs[my_job];
+                        e.photons[my_path - e.first_path] = ph;
+                    } else {
+                        photons[my_path - job.first_path] = ph;
+                    }
                 } else {
                     ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
                     emit_obj = emitter;

@@ -123,3 +123,19 @@ extern "C" uint64_t mirror_dump_rays(void* scene, uint32_t w, uint32_t h, uint64
     }
     return count;
 }
+
+// The kernel's conservative bounds {centre, radius^2}: sphere clusters first, then prisms (analysis helper).
+extern "C" uint32_t mirror_bounds(void* scene, float* out4, uint32_t cap, uint32_t* n_clusters) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    uint32_t n = 0;
+    auto put = [&](const RlF4& b) {
+        if (n < cap) {
+            out4[4 * n] = b.x; out4[4 * n + 1] = b.y; out4[4 * n + 2] = b.z; out4[4 * n + 3] = b.w;
+        }
+        n++;
+    };
+    for (uint32_t k = 0; k < fs.n_clusters; ++k) put(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
+    if (n_clusters) *n_clusters = fs.n_clusters;
+    for (size_t i = 0; i < fs.prisms.size() / RL_PRISM_STRIDE; ++i) put(fs.prisms[RL_PRISM_STRIDE * i + 16]);
+    return n;
+}

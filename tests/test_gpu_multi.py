@@ -216,3 +216,43 @@ def test_bench_runs_its_own_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["dist_backend"] == "gloo"
     assert line["mpaths_per_s"] > 0 and abs(line["segments_per_path"] - 3.54) < 0.1
     assert line["value"] > 0 and "cpu_baseline" not in line
+
+
+def test_concurrent_renders_are_merged_into_one_launch_and_stay_bit_exact(R):
+    """The reference runs one TraceUnit::render per worker thread (app.rs:92-134).  Calls in flight together are
+    merged into one launch by the library (rl_api.hip's batcher); every unit must still receive exactly its own
+    paths: photons bit-equal to the oracle's for that unit's path range, whatever was merged with whatever."""
+    import threading
+    W, H = 160, 90
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    for n, workers in ((1 << 12, 8), (1000, 5)):        # 1000 is not a multiple of the refill size: launched alone
+        units = [R.TraceUnit(i, W, H, n_photons=n) for i in range(workers)]
+        start = threading.Barrier(workers)
+        results, errors = {}, []
+
+        def work(i):
+            try:
+                for rnd in range(3):
+                    first = (rnd * workers + (workers - 1 - i)) * n + 7 * rnd      # not in unit order, not contiguous
+                    start.wait()
+                    units[i].render(scene, seed=6, stream=2, first_path_index=first)
+                    results[(i, rnd)] = (first, units[i].mapped_photons)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+        [t.start() for t in threads]
+        [t.join() for t in threads]
+        assert not errors, errors
+        total_segments = 0
+        for (i, rnd), (first, got) in results.items():
+            want, segs = oscene.render(W, H, 6, 2, first, n, threads=4)
+            assert got.tobytes() == want.tobytes(), (n, i, rnd)
+            total_segments += segs
+        stats = [u.stats() for u in units]
+        assert sum(s[0] for s in stats) == 3 * workers * n and sum(s[1] for s in stats) == total_segments
+        launches = sum(1 for s in stats if s[2] > 0)
+        if n % 256 == 0:
+            assert launches <= workers        # merged launches are accounted to the unit that led them
