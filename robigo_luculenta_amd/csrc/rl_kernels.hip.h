@@ -33,6 +33,7 @@ struct RlSceneLayout {
     uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cull, off_camera, off_cie, off_sphere_obj, total_f4;
     float cull_cmax2; // RlFlatScene::cull_cmax2
     uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
+    uint32_t n_cluster_groups, n_prism_groups; // RlFlatScene: second level of the cull table
 };
 
 struct RlTraceJob {
@@ -59,10 +60,10 @@ struct RlJobEntry {
 enum { RL_ST_ITER, RL_ST_SCAN_LANES, RL_ST_A_ROUNDS, RL_ST_A_LANES, RL_ST_B_ROUNDS, RL_ST_B_LANES, RL_ST_P_ROUNDS, RL_ST_P_LANES,
        RL_ST_SHADE_DIFFUSE, RL_ST_SHADE_GLASS, RL_ST_SHADE_SOAP, RL_ST_END_EMITTER, RL_ST_END_VOID, RL_ST_ANY_GLASS, RL_ST_ANY_SOAP,
        RL_ST_ANY_COLOURED, RL_ST_ANY_GLOSSY, RL_ST_REFILLS, RL_ST_EMIT_BATCHES, RL_ST_EMIT_LANES, RL_ST_A_ITEMS, RL_ST_P_ITEMS,
-       RL_ST_ANY_DIFFUSE,
+       RL_ST_ANY_DIFFUSE, RL_ST_S_ROUNDS, RL_ST_S_LANES, RL_ST_S_ITEMS,
        // shader cycles (s_memtime) a wave spent in each region of the main loop, summed over waves
        RL_ST_T_TOTAL, RL_ST_T_REFILL, RL_ST_T_SMALL, RL_ST_T_DIRECT, RL_ST_T_CLUSTER, RL_ST_T_TAIL, RL_ST_T_PRISM, RL_ST_T_SHADE,
-       RL_ST_T_EMIT, RL_ST_T_A_ROUNDS, RL_ST_T_B_ROUNDS, RL_ST_T_P_ROUNDS, RL_ST_T_CAMERA, RL_ST_COUNT };
+       RL_ST_T_EMIT, RL_ST_T_A_ROUNDS, RL_ST_T_B_ROUNDS, RL_ST_T_P_ROUNDS, RL_ST_T_CAMERA, RL_ST_T_S_ROUNDS, RL_ST_COUNT };
 __device__ unsigned long long rl_stat_counters[48];
 // asm volatile + "memory": ordered against every LDS access, barrier and other timer read (the builtin may be
 // hoisted or sunk by the optimiser); pure ALU work may still drift across a read by a few instructions.
@@ -140,6 +141,7 @@ struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
+    uint32_t ring_s[128];       // (group index << 6) | owner lane: second level of the cull table
     // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior, then
     // the path's index in its RNG stream (lo, hi; both ~0 = no path).  Refilled with all 64 lanes busy.
     float stash[10][64];
@@ -166,13 +168,15 @@ struct RlWaveScratch {
 //     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2, RlF3 o, RlF3 dir,
-                                              uint32_t idle_bit, RlWaveScratch* ws, uint32_t lane RL_TACC_PARAM) {
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2, uint32_t n_cluster_groups,
+                                              uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
+                                              uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
     RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
     RlLdsU32* ring_b = (RlLdsU32*)ws->ring_b;
-    uint32_t a_head = 0, a_tail = 0, b_head = 0, b_tail = 0; // wave-uniform ring indices
+    RlLdsU32* ring_s = (RlLdsU32*)ws->ring_s;
+    uint32_t a_head = 0, a_tail = 0, b_head = 0, b_tail = 0, s_head = 0, s_tail = 0; // wave-uniform ring indices
     const RlF4* sph = sv.spheres;
 
     // Paraboloids, planes and circles: a handful of records, evaluated in registers.
@@ -307,30 +311,74 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 
     RL_T0(t_cluster);
     const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
-    // ---- sphere clusters: bound cull per ray -> ring A ----
-    if (sv.n_clusters != 0) { // even count (rl_scene.cpp pads), two clusters per iteration
-        RlF4 b0 = cull[0], b1 = cull[1];
-#define RL_CLUSTER_CULL(B, K)                                                                       \
-    {                                                                                               \
-        const bool pass = rl_cull_pass(cr, B);                                                      \
-        const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
-        if (m != 0) {                                                                               \
-            if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((K) << 6) | lane;                    \
-            a_tail += (uint32_t)__popcll(m);                                                        \
-            if (a_tail - a_head >= 64u) {                                                           \
-                process_clusters(64u);                                                              \
-                a_head += 64u;                                                                      \
-            }                                                                                       \
-        }                                                                                           \
+    // The cull table (rl_scene.h): level-1 bounds [clusters | prisms], then one group bound per RL_GROUP_G of them.
+    // Every ray is tested against the GROUP bounds with wave-uniform records; the (group, ray) pairs that pass are
+    // compacted into ring S and a ring-S round tests the group's RL_GROUP_G members, one pair per lane with the
+    // owner's cull terms fetched across lanes, pushing the members that pass to ring A (clusters or prisms).
+    const uint32_t n_level1 = RL_GROUP_G * (n_cluster_groups + n_prism_groups);
+    // ---- ring S round.  PROCESS_A(count) runs a ring-A round; ITEM_BASE turns a cull-table index into the
+    // cluster / prism number.
+#define RL_GROUP_ROUND(COUNT, ITEM_BASE, PROCESS_A)                                                    \
+    {                                                                                                   \
+        RL_STAT(RL_ST_S_ROUNDS, 1);                                                                     \
+        RL_STAT(RL_ST_S_LANES, COUNT);                                                                  \
+        RL_T0(t_s);                                                                                     \
+        rl_wave_sync();                                                                                 \
+        const uint32_t e = ring_s[(s_head + lane) & 127u];                                              \
+        const uint32_t owner = e & 63u;                                                                 \
+        const uint32_t first = RL_GROUP_G * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
+        RlCullRay r;                                                                                    \
+        r.d.x = __shfl(cr.d.x, (int)owner); r.d.y = __shfl(cr.d.y, (int)owner); r.d.z = __shfl(cr.d.z, (int)owner); \
+        r.m.x = __shfl(cr.m.x, (int)owner); r.m.y = __shfl(cr.m.y, (int)owner); r.m.z = __shfl(cr.m.z, (int)owner); \
+        r.p = __shfl(cr.p, (int)owner);                                                                 \
+        r.s = __shfl(cr.s, (int)owner);                                                                 \
+        r.q = __shfl(cr.q, (int)owner);                                                                 \
+        if (lane >= (COUNT)) r.q = __builtin_inff(); /* lanes beyond the round never pass */            \
+        _Pragma("nounroll") for (uint32_t j = 0; j < RL_GROUP_G; ++j) {                                 \
+            const RlF4 bnd = cull[first + j];                                                           \
+            const bool pass = rl_cull_pass(r, bnd);                                                     \
+            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
+            if (m != 0) {                                                                               \
+                if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((first + j - (ITEM_BASE)) << 6) | owner; \
+                a_tail += (uint32_t)__popcll(m);                                                        \
+                if (a_tail - a_head >= 64u) {                                                           \
+                    PROCESS_A(64u);                                                                     \
+                    a_head += 64u;                                                                      \
+                }                                                                                       \
+            }                                                                                           \
+        }                                                                                               \
+        rl_wave_sync();                                                                                 \
+        RL_T1(RL_ST_T_S_ROUNDS, t_s);                                                                   \
     }
-        for (uint32_t k = 0; k < sv.n_clusters; k += 2) {
-            const RlF4 n0 = cull[k + 2], n1 = cull[k + 3]; // prefetch (the table has slack at its end)
-            RL_CLUSTER_CULL(b0, k)
-            RL_CLUSTER_CULL(b1, k + 1)
-            b0 = n0;
-            b1 = n1;
-        }
-#undef RL_CLUSTER_CULL
+    // ---- level 2, wave-uniform: group bounds [FIRST, FIRST + COUNT) of the cull table -> ring S ----
+#define RL_GROUP_CULLS(FIRST_GROUP, N_GROUPS, ITEM_BASE, PROCESS_A)                                     \
+    {                                                                                                   \
+        const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
+        RlF4 g0 = gb[0];                                                                                \
+        for (uint32_t g = 0; g < (N_GROUPS); ++g) {                                                     \
+            const RlF4 g1 = gb[g + 1]; /* prefetch (the table has slack at its end) */                  \
+            const bool pass = rl_cull_pass(cr, g0);                                                     \
+            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
+            if (m != 0) {                                                                               \
+                if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (((FIRST_GROUP) + g) << 6) | lane;    \
+                s_tail += (uint32_t)__popcll(m);                                                        \
+                if (s_tail - s_head >= 64u) {                                                           \
+                    RL_GROUP_ROUND(64u, ITEM_BASE, PROCESS_A)                                           \
+                    s_head += 64u;                                                                      \
+                }                                                                                       \
+            }                                                                                           \
+            g0 = g1;                                                                                    \
+        }                                                                                               \
+        if (s_tail != s_head) {                                                                         \
+            const uint32_t left = s_tail - s_head;                                                      \
+            RL_GROUP_ROUND(left, ITEM_BASE, PROCESS_A)                                                  \
+            s_head = s_tail;                                                                            \
+        }                                                                                               \
+    }
+    // ---- sphere clusters: group culls -> ring S -> cluster bounds -> ring A -> members -> ring B ----
+    if (n_cluster_groups != 0) {
+        RL_GROUP_CULLS(0u, n_cluster_groups, 0u, process_clusters)
+        RL_STAT(RL_ST_S_ITEMS, s_tail);
         if (a_tail != a_head) process_clusters(a_tail - a_head);
         a_head = a_tail;
         RL_STAT(RL_ST_A_ITEMS, a_tail);
@@ -374,28 +422,17 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();
         RL_T1(RL_ST_T_P_ROUNDS, t_p);
     };
-    const RlF4* pcull = cull + sv.n_clusters;
-    RlF4 pb = pcull[0];
-    for (uint32_t i = 0; i < sv.n_prisms; ++i) {
-        const RlF4 b = pb;
-        pb = pcull[i + 1]; // prefetch (slack record at the end of the table)
-        const bool pass = rl_cull_pass(cr, b);
-        const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
-        if (m != 0) {
-            if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = (i << 6) | lane;
-            a_tail += (uint32_t)__popcll(m);
-            if (a_tail - a_head >= 64u) {
-                process_prisms(64u);
-                a_head += 64u;
-            }
-        }
+    if (n_prism_groups != 0) {
+        RL_GROUP_CULLS(n_cluster_groups, n_prism_groups, RL_GROUP_G * n_cluster_groups, process_prisms)
     }
+#undef RL_GROUP_CULLS
+#undef RL_GROUP_ROUND
     if (a_tail != a_head) process_prisms(a_tail - a_head);
     RL_T1(RL_ST_T_PRISM, t_prism);
 #ifdef RL_STATS
     {
         uint32_t cluster_items = 0;
-        if (sv.n_clusters != 0) cluster_items = a_head_after_clusters;
+        if (n_cluster_groups != 0) cluster_items = a_head_after_clusters;
         RL_STAT(RL_ST_P_ITEMS, a_tail - cluster_items);
     }
 #endif
@@ -592,8 +629,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
         }
         RL_T1(RL_ST_T_REFILL, t_refill);
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, p.origin, p.direction,
-                                       active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
+        const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+                                       p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
             const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? (rl_f2u(sv.objects[2 * hit.obj].x) >> 8) : 99u;

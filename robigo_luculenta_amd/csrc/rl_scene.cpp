@@ -341,6 +341,146 @@ RlF4 cluster_bound(const std::vector<SphereIn>& sph, const std::vector<uint32_t>
     return b;
 }
 
+// ---- second level of the cull table: groups of RL_GROUP_G neighbouring bounds ------------------------------
+
+double bound_radius(const RlF4& b) { return b.w > 0.0f ? std::sqrt((double)b.w) : 0.0; } // {c, R^2}; R^2 = +inf -> inf
+
+// Partitions bounds (given as {centre, radius^2}) into groups of at most RL_GROUP_G: recursive median cuts along the
+// longest axis into leaves of exactly RL_GROUP_G (the last may be short), then a few rounds of capacity-limited
+// re-assignment to the nearest group centre (the same scheme as the sphere clusters above).
+void split_groups(const std::vector<RlF4>& b, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out) {
+    if (idx.size() <= RL_GROUP_G) {
+        if (!idx.empty()) out.push_back(idx);
+        return;
+    }
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i : idx) {
+        const double c[3] = {b[i].x, b[i].y, b[i].z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], c[a]);
+            hi[a] = std::max(hi[a], c[a]);
+        }
+    }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+    auto coord = [&](uint32_t i) { return axis == 0 ? b[i].x : axis == 1 ? b[i].y : b[i].z; };
+    std::sort(idx.begin(), idx.end(), [&](uint32_t p, uint32_t q) { return coord(p) < coord(q) || (coord(p) == coord(q) && p < q); });
+    size_t left = ((idx.size() / 2 + RL_GROUP_G - 1) / RL_GROUP_G) * RL_GROUP_G;
+    if (left >= idx.size()) left = idx.size() - RL_GROUP_G;
+    split_groups(b, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out);
+    split_groups(b, std::vector<uint32_t>(idx.begin() + left, idx.end()), out);
+}
+
+void refine_groups(const std::vector<RlF4>& b, std::vector<std::vector<uint32_t>>& groups) {
+    const size_t k = groups.size();
+    if (k < 2) return;
+    std::vector<uint32_t> all;
+    for (const auto& g : groups) all.insert(all.end(), g.begin(), g.end());
+    std::sort(all.begin(), all.end());
+    for (int iteration = 0; iteration < 24; ++iteration) {
+        std::vector<double> cx(k, 0), cy(k, 0), cz(k, 0);
+        for (size_t j = 0; j < k; ++j) {
+            for (uint32_t i : groups[j]) {
+                cx[j] += b[i].x; cy[j] += b[i].y; cz[j] += b[i].z;
+            }
+            const double n = (double)std::max<size_t>(1, groups[j].size());
+            cx[j] /= n; cy[j] /= n; cz[j] /= n;
+        }
+        auto dist2 = [&](uint32_t i, size_t j) {
+            const double dx = b[i].x - cx[j], dy = b[i].y - cy[j], dz = b[i].z - cz[j];
+            return dx * dx + dy * dy + dz * dz;
+        };
+        std::vector<std::pair<double, uint32_t>> order;
+        for (uint32_t i : all) {
+            double best = 1e300, second = 1e300;
+            for (size_t j = 0; j < k; ++j) {
+                const double d = dist2(i, j);
+                if (d < best) { second = best; best = d; }
+                else if (d < second) second = d;
+            }
+            order.push_back({std::sqrt(best) - std::sqrt(second), i});
+        }
+        std::sort(order.begin(), order.end());
+        std::vector<std::vector<uint32_t>> next(k);
+        for (const auto& entry : order) {
+            const uint32_t i = entry.second;
+            size_t pick = k;
+            double pick_d = 1e300;
+            for (size_t j = 0; j < k; ++j) {
+                if (next[j].size() >= RL_GROUP_G) continue;
+                const double d = dist2(i, j);
+                if (d < pick_d) { pick_d = d; pick = j; }
+            }
+            next[pick].push_back(i);
+        }
+        bool same = true;
+        for (size_t j = 0; j < k && same; ++j) {
+            std::sort(next[j].begin(), next[j].end());
+            std::vector<uint32_t> old = groups[j];
+            std::sort(old.begin(), old.end());
+            same = old == next[j];
+        }
+        groups = next;
+        if (same) break;
+    }
+    std::vector<std::vector<uint32_t>> kept;
+    for (auto& g : groups)
+        if (!g.empty()) kept.push_back(g);
+    groups = kept;
+}
+
+// Bounding sphere {centre, radius^2} of a group of bounding spheres, inflated by 0.1 % + 1e-3 (the members carry
+// their own 5 % already; this only has to cover the rounding of this computation and of the float conversion).
+RlF4 group_bound(const std::vector<RlF4>& b, const std::vector<uint32_t>& members) {
+    RlF4 r;
+    r.x = r.y = r.z = 0.0f;
+    r.w = std::numeric_limits<float>::infinity();
+    for (uint32_t i : members)
+        if (!(b[i].w < 1e30f)) return r; // an unbounded member: the group is always reached
+    double c[3] = {0, 0, 0};
+    for (uint32_t i : members) {
+        c[0] += b[i].x; c[1] += b[i].y; c[2] += b[i].z;
+    }
+    for (int a = 0; a < 3; ++a) c[a] /= (double)members.size();
+    auto reach = [&](uint32_t i) {
+        const double dx = b[i].x - c[0], dy = b[i].y - c[1], dz = b[i].z - c[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz) + bound_radius(b[i]);
+    };
+    for (int it = 0; it < 64; ++it) {
+        uint32_t far = members[0];
+        for (uint32_t i : members)
+            if (reach(i) > reach(far)) far = i;
+        const double step = 0.5 / (it + 2.0);
+        c[0] += (b[far].x - c[0]) * step; c[1] += (b[far].y - c[1]) * step; c[2] += (b[far].z - c[2]) * step;
+    }
+    r.x = (float)c[0]; r.y = (float)c[1]; r.z = (float)c[2];
+    c[0] = r.x; c[1] = r.y; c[2] = r.z; // measure from the centre as it will be stored
+    double radius = 0;
+    for (uint32_t i : members) radius = std::max(radius, reach(i));
+    radius = radius * 1.001 + 1e-3;
+    r.w = (float)(radius * radius);
+    if (!(radius < 1e15)) r.w = std::numeric_limits<float>::infinity();
+    return r;
+}
+
+// Orders `bounds` so that each group's members are consecutive; returns the new order (old indices) and, per
+// group, its members as positions in the new order.
+std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vector<std::vector<uint32_t>>* groups_out) {
+    std::vector<uint32_t> idx(bounds.size());
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::vector<std::vector<uint32_t>> groups;
+    split_groups(bounds, idx, groups);
+    refine_groups(bounds, groups);
+    std::vector<uint32_t> order;
+    for (std::vector<uint32_t>& g : groups) {
+        std::sort(g.begin(), g.end());
+        order.insert(order.end(), g.begin(), g.end());
+    }
+    *groups_out = groups;
+    return order;
+}
+
 } // namespace
 
 uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, RlCameraDesc* camera) {
@@ -462,9 +602,24 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     std::vector<std::vector<uint32_t>> clusters;
     split_clusters(sph_in, clustered, clusters);
     refine_clusters(sph_in, clusters);
+    // Second level: clusters whose bounds are neighbours become consecutive, RL_GROUP_G per group; a short group is
+    // filled up with never-reached dummy clusters so that a cluster's number is also its position in the cull table.
+    const RlF4 never = dummy; // as a bound {c, R^2 = -inf}: fails every cull test, host and device
+    {
+        std::vector<RlF4> bounds;
+        for (std::vector<uint32_t>& members : clusters) bounds.push_back(cluster_bound(sph_in, members));
+        std::vector<std::vector<uint32_t>> groups;
+        order_by_groups(bounds, &groups);
+        std::vector<std::vector<uint32_t>> padded;
+        for (const std::vector<uint32_t>& g : groups) {
+            for (uint32_t k : g) padded.push_back(clusters[k]);
+            for (size_t pad = g.size(); pad < RL_GROUP_G; ++pad) padded.push_back(std::vector<uint32_t>());
+        }
+        clusters = padded;
+    }
     for (std::vector<uint32_t>& members : clusters) {
         std::sort(members.begin(), members.end()); // ascending object order inside a cluster
-        fs.spheres.push_back(cluster_bound(sph_in, members));
+        fs.spheres.push_back(members.empty() ? never : cluster_bound(sph_in, members));
         fs.sphere_obj.push_back(RL_HIT_NONE);
         for (uint32_t k : members) place(k);
         for (size_t pad = members.size(); pad < RL_CLUSTER_K; ++pad) {
@@ -473,14 +628,33 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         }
     }
     fs.n_clusters = (uint32_t)clusters.size();
-    // The kernel walks the clusters two at a time: pad to an even count with a cluster that can not
-    // be reached (bound radius^2 = -inf fails every cull) and holds only dummies.
-    if (fs.n_clusters & 1u) {
-        fs.spheres.resize(fs.spheres.size() + RL_CLUSTER_STRIDE, dummy);
-        fs.sphere_obj.resize(fs.spheres.size(), RL_HIT_NONE);
-        fs.n_clusters += 1;
+    fs.n_cluster_groups = fs.n_clusters / RL_GROUP_G;
+    // The prisms likewise: reorder the records (scan order is irrelevant: ties are broken by the object index each
+    // record carries), fill short groups with dummy prisms, point the prism objects at their new position.
+    uint32_t n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
+    if (n_prisms != 0) {
+        std::vector<RlF4> bounds;
+        for (uint32_t i = 0; i < n_prisms; ++i) bounds.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
+        std::vector<std::vector<uint32_t>> groups;
+        order_by_groups(bounds, &groups);
+        std::vector<RlF4> sorted;
+        for (const std::vector<uint32_t>& g : groups) {
+            for (uint32_t k : g) {
+                const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * k];
+                fs.objects[2 * rl_f2u(pr[1].w)].y = rl_u2f((uint32_t)(sorted.size() / RL_PRISM_STRIDE)); // group index = position
+                sorted.insert(sorted.end(), pr, pr + RL_PRISM_STRIDE);
+            }
+            for (size_t pad = g.size(); pad < RL_GROUP_G; ++pad) {
+                sorted.resize(sorted.size() + RL_PRISM_STRIDE - 1, RlF4{0.0f, 0.0f, 0.0f, 0.0f});
+                sorted.push_back(never);
+            }
+        }
+        fs.prisms = sorted;
+        n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
     }
-    // Cull table for the kernel: {c, |c|^2 - R^2} per cluster bound, then per prism bound.
+    fs.n_prism_groups = n_prisms / RL_GROUP_G;
+    // Cull table for the kernel, {c, |c|^2 - R^2} per bound: clusters, prisms, then one group bound per RL_GROUP_G
+    // clusters and per RL_GROUP_G prisms.
     fs.cull_cmax2 = 0.0f;
     auto add_bound = [&](const RlF4& b) {
         const double c2 = (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z;
@@ -489,8 +663,17 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         fs.cull_bounds.push_back(r);
         if (std::isfinite(b.w)) fs.cull_cmax2 = std::max(fs.cull_cmax2, (float)c2 * 1.0001f);
     };
-    for (uint32_t k = 0; k < fs.n_clusters; ++k) add_bound(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
-    for (size_t i = 0; i < fs.prisms.size() / RL_PRISM_STRIDE; ++i) add_bound(fs.prisms[RL_PRISM_STRIDE * i + 16]);
-    fs.cull_bounds.push_back(dummy); // one record of slack for the kernel's prefetch
+    std::vector<RlF4> level1;
+    for (uint32_t k = 0; k < fs.n_clusters; ++k) level1.push_back(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
+    for (uint32_t i = 0; i < n_prisms; ++i) level1.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
+    for (const RlF4& b : level1) add_bound(b);
+    for (size_t first = 0; first < level1.size(); first += RL_GROUP_G) {
+        std::vector<uint32_t> members;
+        for (size_t j = first; j < first + RL_GROUP_G; ++j)
+            if (!(level1[j].w == never.w)) members.push_back((uint32_t)j);
+        add_bound(members.empty() ? never : group_bound(level1, members));
+    }
+    fs.cull_bounds.push_back(dummy); // slack for the kernel's prefetch
+    fs.cull_bounds.push_back(dummy);
     return RL_OK;
 }

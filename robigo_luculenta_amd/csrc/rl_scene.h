@@ -43,6 +43,9 @@ struct alignas(16) RlF4 {
 #define RL_CLUSTER_K 10                        // spheres per cluster (tuned on MI355X: DESIGN.md)
 #endif
 #define RL_CLUSTER_STRIDE (RL_CLUSTER_K + 1)   // + the bound record in front (odd stride: LDS banks)
+#ifndef RL_GROUP_G
+#define RL_GROUP_G 3                           // bounds per second-level group of the cull table (tuned: DESIGN.md)
+#endif
 
 // Everything the per-path code needs to read; pointers are device or host memory depending on
 // who built the view.
@@ -58,7 +61,7 @@ struct RlSceneView {
     uint32_t n_direct;         // direct spheres: records [0, n_direct)
     uint32_t n_direct_padded;  // multiple of 4; records [n_direct, n_direct_padded + 4) are dummies
     uint32_t cluster_base;     // first cluster record (= n_direct_padded + 4)
-    uint32_t n_clusters;       // even; each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
+    uint32_t n_clusters;       // each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
     // 3 records: the 10 floats of RlCameraDesc, then screen_distance = 1 / tan(field_of_view / 2)
     // (camera.rs:56, constant per scene).  Read from memory where a path starts instead of being held
     // in a dozen scalar registers across the whole persistent loop.
@@ -68,9 +71,15 @@ struct RlSceneView {
 // Host-side flattened scene (built once by rl_scene_create).
 struct RlFlatScene {
     std::vector<RlF4> spheres, planes, parabs, prisms, objects;
-    // Device-only copy of every bound, clusters first then prisms, as {centre.xyz, |centre|^2 - radius^2}:
-    // the form the kernel's expanded cull test consumes (rl_kernels.hip.h), contiguous for uniform fetches.
+    // Device-only cull table, every bound as {centre.xyz, |centre|^2 - radius^2}: the form the kernel's expanded cull
+    // test consumes (rl_kernels.hip.h).  Two levels: the cluster bounds, then the prism bounds, each list padded to
+    // a multiple of RL_GROUP_G with never-reached dummies and ordered so that RL_GROUP_G consecutive entries are
+    // spatial neighbours (clusters and prisms are stored in that order too); then one GROUP bound -- the bounding
+    // sphere of the RL_GROUP_G bounds it covers -- per group of clusters, then per group of prisms.  A ray is tested
+    // against the group bounds in a wave-uniform loop and only the (group, ray) pairs that pass go on to the
+    // group's members.  Not in the reference; conservative like the bounds themselves.
     std::vector<RlF4> cull_bounds;
+    uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [G * n_cluster_groups][G * n_prism_groups][groups][groups][slack]
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView

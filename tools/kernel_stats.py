@@ -15,9 +15,9 @@ from robigo_luculenta_amd import _lib  # noqa: E402
 
 NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_rounds", "p_lanes", "shade_diffuse",
          "shade_glass", "shade_soap", "end_emitter", "end_void", "any_glass", "any_soap", "any_coloured", "any_glossy",
-         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse",
+         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse", "s_rounds", "s_lanes", "s_items",
          "t_total", "t_refill", "t_small", "t_direct", "t_cluster", "t_tail", "t_prism", "t_shade", "t_emit", "t_a_rounds",
-         "t_b_rounds", "t_p_rounds", "t_camera"]
+         "t_b_rounds", "t_p_rounds", "t_camera", "t_s_rounds"]
 
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 which = sys.argv[2] if len(sys.argv) > 2 else "demo"
@@ -37,7 +37,7 @@ paths, segs, ms = t.stats()
 it = float(c["iter"])
 print("%s: %d paths, %d rays, %d wave-iterations, %.1f rays per wave-iteration (of 64)" % (which, paths, segs, c["iter"], segs / it))
 print("  scan lanes active            %5.1f %%" % (100.0 * c["scan_lanes"] / (64 * it)))
-for key, label in (("a", "cluster-member rounds"), ("b", "sphere-tail rounds    "), ("p", "prism CSG rounds     ")):
+for key, label in (("s", "group (ring S) rounds "), ("a", "cluster-member rounds"), ("b", "sphere-tail rounds    "), ("p", "prism CSG rounds     ")):
     r, l = c[key + "_rounds"], c[key + "_lanes"]
     print("  %s  %.2f per iteration, %4.1f %% of lanes filled" % (label, r / it, 100.0 * l / max(1, 64 * r)))
 print("  (cluster, ray) pairs         %.1f per iteration = %.2f per ray;  (prism, ray) pairs %.1f = %.2f per ray"
@@ -56,7 +56,8 @@ if tt > 0:
     print("  wave cycles per iteration %.0f (shader clock); share of a wave's time by region:" % (tt / it))
     rows = (("refill (stash hand-out + camera rays)", "t_refill"), ("  of which rl_begin_path", "t_camera"),
             ("planes / circles / paraboloids", "t_small"), ("direct spheres", "t_direct"),
-            ("cluster culls + member rounds", "t_cluster"), ("  of which member rounds", "t_a_rounds"),
+            ("cluster group culls + rounds", "t_cluster"), ("  of which member rounds", "t_a_rounds"),
+            ("group (ring S) rounds, clusters and prisms", "t_s_rounds"),
             ("final sphere-tail flush", "t_tail"), ("  all sphere-tail rounds", "t_b_rounds"),
             ("prism culls + CSG rounds", "t_prism"), ("  of which CSG rounds", "t_p_rounds"),
             ("bounce (hit completion, material, roulette)", "t_shade"), ("emitter queue + splat", "t_emit"))
