@@ -156,7 +156,8 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms):
         "wave_time": ({"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                        "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]} if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None),
         "profiled_launch_ms": d["kernel_ns"] / 1e6, "profiled_rays_per_launch": d["rays_per_launch"],
-        "rays_per_launch_match": abs(d["rays_per_launch"] - rays_per_launch) <= 1e-6 * rays_per_launch,
+        # the same workload: launches of the same size over other path ranges differ by a few ppm in ray count
+        "rays_per_launch_match": abs(d["rays_per_launch"] - rays_per_launch) <= 1e-3 * rays_per_launch,
     }
     traffic = None
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
