@@ -236,6 +236,7 @@ def main():
                          "through host memory, ranks may share a GPU -- for exercising the N > 1 path on a 1-GPU box")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the HSA runtime starts: dmabuf IPC for RCCL
     from robigo_luculenta_amd import distributed as D
     rank, local_rank, world = D.env_rank()
     if world == 1 and args.gpus > 1:
@@ -252,10 +253,21 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     device = local_rank % R.device_count() if args.dist_backend == "gloo" else local_rank
     D.init_control_plane(rank, world)
-    comm = None
+    comm, exchange_note = None, None
     if world > 1 and args.dist_backend == "rccl":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        comm = D.make_comm(R, rank, world, device)
+        # The library's RCCL communicator.  Should it fail to come up on ANY rank (a box without usable xGMI / IPC),
+        # every rank falls back to the host-staged exchange together and the line says so -- a measured line with
+        # a slower exchange is worth more than no line.
+        try:
+            comm = D.make_comm(R, rank, world, device)
+            failed = 0.0
+        except Exception as e:  # noqa: BLE001
+            exchange_note, failed = "rl_comm_init_rank failed on rank %d: %s" % (rank, e), 1.0
+        _, (n_failed,) = D.aggregate(0.0, [failed])
+        if n_failed:
+            comm = None
+            exchange_note = exchange_note or "rl_comm_init_rank failed on another rank"
+            args.dist_backend = "gloo (fallback: %s)" % exchange_note
 
     objs, cam, W, H, label = scene_of(R, args.config)
     scene = R.Scene(objs, cam, device=device)

@@ -328,10 +328,12 @@ typedef struct RlAppConfig {
                                     unit is one unit per rank, rank r uses RNG stream `stream + r`, and Task::Gather
                                     sums the ranks' plot buffers onto rank 0 first (rl_plot_unit_reduce over xGMI for
                                     distinct GPUs, rl_plot_unit_add for ranks that share one) */
-    int queued_trace;            /* un-fused mode.  0 (default): a Trace task is the blocking rl_trace_unit_render, like a
-                                    reference worker -- concurrent workers' calls are merged into one launch (see there);
-                                    non-zero: the launch is queued and the worker moves on (the device orders Plot after
-                                    Trace by itself); measured slower at the reference's task size */
+    int queued_trace;            /* 0 (default): a worker waits for the launch its task issued -- un-fused, a Trace task is the
+                                    blocking rl_trace_unit_render, like a reference worker, and concurrent workers' calls are
+                                    merged into one launch (see there); fused, a Plot task waits for its launch.  Non-zero: the
+                                    launch is queued and the worker moves on (the device orders Plot after Trace and Gather
+                                    after Plot by itself; a unit's previous launch is waited for before it is used again).
+                                    Measured slower un-fused, equal fused, at the reference's task size */
     const int* devices;          /* n_devices device indices, rank 0 first (gather, tonemap and output live there);
                                     NULL = device, device + 1, ...  A device may be listed more than once. */
 } RlAppConfig;

@@ -84,7 +84,15 @@ def aggregate(elapsed_s, counters):
 
 
 def make_comm(R, rank, world, device):
-    """One RCCL rank of the library (rl_comm_init_rank) for this process; the id travels over the control plane."""
-    uid = R.Comm.unique_id() if rank == 0 else None
-    uid = broadcast_bytes(uid, 128, root=0)
-    return R.Comm(uid, world, rank, device)
+    """One RCCL rank of the library (rl_comm_init_rank) for this process; the id travels over the control plane.
+    If rank 0 cannot obtain an id (RCCL missing), every rank raises together instead of waiting for a peer."""
+    payload, error = bytes(129), None
+    if rank == 0:
+        try:
+            payload = b"\x01" + R.Comm.unique_id()
+        except Exception as e:  # noqa: BLE001
+            error = e
+    payload = broadcast_bytes(payload, 129, root=0)
+    if payload[0] != 1:
+        raise error if error is not None else RuntimeError("rank 0 could not create an RCCL communicator id")
+    return R.Comm(payload[1:], world, rank, device)
