@@ -22,24 +22,32 @@ def cases():
     g = np.load(FIXTURE)
     i = 0
     while "case%d_params" % i in g.files:
-        w, h, seed, stream, first, n = (int(v) for v in g["case%d_params" % i])
+        w, h, seed, stream, first, n, which = (int(v) for v in g["case%d_params" % i])
         want = np.zeros(n, dtype=O.PHOTON_DTYPE)
         for k in ("x", "y", "probability", "wavelength"):
             want[k] = g["case%d_%s" % (i, k)]
-        yield (w, h, seed, stream, first, n), want, int(g["case%d_segments" % i][0])
+        yield which, (w, h, seed, stream, first, n), want, int(g["case%d_segments" % i][0])
         i += 1
 
 
+def scene_desc(R_or_mirror, which):
+    """(objects, camera) of fixture scene 0 demo, 1 glass stress, 2 demo with 158 seeds -- from the PRODUCT's own
+    generators, which the independent script does not use."""
+    return R_or_mirror.builtin_scene_desc(*((0, 0), (1, 0), (0, 158))[which])
+
+
 def test_oracle_matches_the_independent_restatement():
-    objs, cam = O.demo_scene_desc(0)
-    scene = O.Scene(objs, cam)
-    total = 0
-    for (w, h, seed, stream, first, n), want, segs in cases():
+    import robigo_luculenta_amd as R   # host-only generators: no GPU needed
+    total, scenes = 0, set()
+    for which, (w, h, seed, stream, first, n), want, segs in cases():
+        objs, cam = scene_desc(R, which)
+        scene = O.Scene(objs.view(O.OBJECT_DTYPE), O.RlCameraDesc.from_buffer_copy(bytes(cam)))
         got, got_segs = scene.render(w, h, seed, stream, first, n, threads=4)
-        assert got.tobytes() == want.tobytes()
+        assert got.tobytes() == want.tobytes(), which
         assert got_segs == segs
         total += n
-    assert total >= 20000
+        scenes.add(which)
+    assert total >= 28000 and scenes == {0, 1, 2}
 
 
 def test_fixture_is_reproducible_from_the_script():
@@ -49,10 +57,9 @@ def test_fixture_is_reproducible_from_the_script():
 @pytest.mark.gpu
 def test_gpu_matches_the_independent_restatement():
     import robigo_luculenta_amd as R
-    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
-    scene = R.Scene(objs, cam)
     for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
-        for (w, h, seed, stream, first, n), want, segs in cases():
+        for which, (w, h, seed, stream, first, n), want, segs in cases():
+            scene = R.Scene(*scene_desc(R, which))
             unit = R.TraceUnit(0, w, h, n_photons=n)
             unit.set_fetch(fetch)
             unit.render(scene, seed=seed, stream=stream, first_path_index=first)

@@ -471,7 +471,11 @@ class SoapBubble:
 def powi2(x): return F(x) * F(x)
 
 
-def set_up_scene(seeds=100):
+def set_up_scene(seeds=100, prism_rings=(17.0,), fixed_only=False):
+    """app.rs:166-325.  seeds / prism_rings / fixed_only parametrise the two derived BASELINE scenes exactly as
+    SURVEY 8(d) defines them: config 5 = the same generator with seeds = 158; config 3 ("dispersive-glass stress") =
+    the seven fixed objects without the spheres plus three rings of prisms built by the recipe of app.rs:287-325 at
+    prism_radius 10, 17, 24."""
     objects = []
     sun_radius = F(5.0)
     sun_position = V(F(0), F(0), F(0))
@@ -498,6 +502,8 @@ def set_up_scene(seeds=100):
     seed_size = F(0.8)
     seed_scale = F(1.5)
     first_seed = int(powi2(sun_radius / seed_scale + F(1.0)) + F(0.5))
+    if fixed_only:
+        seeds, first_seed_bubbles = 0, None
     for i in range(first_seed, first_seed + seeds):
         phi = F(i) * gamma
         r = sqrt(F(i)) * seed_scale
@@ -509,7 +515,7 @@ def set_up_scene(seeds=100):
         r = sqrt(F(i) + F(0.5)) * seed_scale
         position = V(cos(phi) * r, sin(phi) * r, (r - sun_radius) * F(-0.25)) + sun_position
         objects.append((Sphere(position, seed_size * F(0.5)), GlossyMirror(0.1)))
-    for i in range(first_seed // 2, first_seed + seeds):
+    for i in (() if fixed_only else range(first_seed // 2, first_seed + seeds)):
         phi = F(-i) * gamma
         r = sqrt(F(i)) * seed_scale * F(1.5)
         position = V(cos(phi) * r, sin(phi) * r, (r - sun_radius) * F(1.5) + sun_radius * F(2.0)) + sun_position
@@ -517,9 +523,8 @@ def set_up_scene(seeds=100):
 
     prisms = 11
     prism_angle = PI * F(2.0) / F(prisms)
-    prism_radius = F(17.0)
     prism_height = F(8.0)
-    for i in range(prisms):
+    for prism_radius, i in ((F(pr), i) for pr in prism_rings for i in range(prisms)):
         for ofs, radius, phi_ofs, h in ((F(0.0), F(1.0), F(0.0), F(1.0)), (F(0.5) * prism_angle, F(1.2), PI * F(0.5), F(1.5))):
             phi = F(i) * prism_angle + ofs
             position = V(cos(phi) * prism_radius * radius, sin(phi) * prism_radius * radius, F(0.0))
@@ -629,19 +634,22 @@ def render(objects, aspect_ratio, seed, stream, first_path, n_paths):
     return x, y, probability, wavelength, segments
 
 
-CASES = (  # (width, height, seed, stream, first_path, n_paths)
-    (1280, 720, 1, 0, 0, 16384),
-    (1920, 1080, 7, 3, (1 << 33) + 12345, 4096),   # another stream / seed, path indices beyond 32 bits
+CASES = (  # (scene, width, height, seed, stream, first_path, n_paths); scene: 0 demo, 1 glass stress, 2 demo(seeds=158)
+    (0, 1280, 720, 1, 0, 0, 16384),
+    (0, 1920, 1080, 7, 3, (1 << 33) + 12345, 4096),   # another stream / seed, path indices beyond 32 bits
+    (1, 1280, 720, 1, 0, 0, 4096),                    # BASELINE config 3
+    (2, 1920, 1080, 1, 2, 1000, 4096),                # BASELINE config 5 (513 objects)
 )
 
 
 def compute():
     _philox_kat()
-    objects = set_up_scene()
+    scenes = {0: set_up_scene(), 1: set_up_scene(fixed_only=True, prism_rings=(10.0, 17.0, 24.0)), 2: set_up_scene(seeds=158)}
+    assert [len(scenes[k]) for k in (0, 1, 2)] == [339, 73, 513]
     out = {}
-    for i, (w, h, seed, stream, first, n) in enumerate(CASES):
-        x, y, p, wl, segs = render(objects, F(w) / F(h), seed, stream, first, n)
-        out["case%d_params" % i] = np.array([w, h, seed, stream, first, n], dtype=np.uint64)
+    for i, (which, w, h, seed, stream, first, n) in enumerate(CASES):
+        x, y, p, wl, segs = render(scenes[which], F(w) / F(h), seed, stream, first, n)
+        out["case%d_params" % i] = np.array([w, h, seed, stream, first, n, which], dtype=np.uint64)
         out["case%d_x" % i], out["case%d_y" % i], out["case%d_probability" % i], out["case%d_wavelength" % i] = x, y, p, wl
         out["case%d_segments" % i] = np.array([segs], dtype=np.uint64)
     return out
