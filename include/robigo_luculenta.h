@@ -171,6 +171,12 @@ int rl_trace_unit_render_async(RlTraceUnit* unit, const RlScene* scene, uint64_t
  * rl_trace_unit_sync() or any download waits for it. */
 int rl_trace_unit_render_fused(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
+/* The same, complete on return, for hosts whose workers wait for their task anyway (the reference's do): calls in
+ * flight together on units of one device (same scene, seed, stream, image size; n_paths a multiple of 64) are merged
+ * into ONE launch that splats into every call's plot unit -- the batches of several Plot tasks share one drain tail.
+ * Results are those of separate calls up to the order of the float atomics. */
+int rl_trace_unit_render_fused_sync(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
+                                    uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
 int rl_trace_unit_sync(RlTraceUnit* unit);
 /* Copies mapped_photons (trace_unit.rs:56) to host memory; `out` holds n_photons entries. */
 int rl_trace_unit_photons(RlTraceUnit* unit, RlMappedPhoton* out);

@@ -125,6 +125,10 @@ class TraceUnit(_Handle):
         check(lib.rl_trace_unit_render_fused(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index,
                                              n_paths))
 
+    def render_fused_sync(self, scene, plot_unit, n_paths, seed=1, stream=0, first_path_index=0):
+        """Blocking fused render; concurrent calls (several threads) are merged into one launch."""
+        check(lib.rl_trace_unit_render_fused_sync(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index, n_paths))
+
     def sync(self):
         check(lib.rl_trace_unit_sync(self._h))
 

@@ -94,7 +94,7 @@ struct RlTraceUnit {
     RlJobEntry* job_table;            // device copy of a merged launch's job list (RL_MAX_MERGED_JOBS entries)
     std::vector<RlJobEntry> job_host; // its host source: must outlive the asynchronous copy
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
-    bool tuned_stage, tuned_fused; // kernel variant,
+    bool tuned_stage, tuned_fused, tuned_multi; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
 };
 
@@ -150,12 +150,25 @@ int drain_events(RlTraceUnit* u) {
 #define RL_MAX_MERGED_JOBS 64
 #define RL_MAX_LAUNCHES_IN_FLIGHT 2
 
-// One launch of the trace kernel on u's stream.  `merged` (may be null) lists the units whose renders this launch
-// carries, all with u's batch size: path offsets [k * n_photons, (k + 1) * n_photons) of the launch are
-// merged[k]'s paths first_paths[k] .. and fill merged[k]'s mapped_photons.
+// One render call inside a merged launch: un-fused (plot == nullptr) it fills unit->mapped_photons with n_paths =
+// unit->n_photons paths, fused it splats n_paths paths into plot's buffer.
+struct MergedJob {
+    RlTraceUnit* unit;
+    RlPlotUnit* plot;
+    uint64_t first_path, n_paths;
+};
+
+// One launch of the trace kernel on u's stream.  `merged` (may be null) lists the calls this launch carries (all
+// fused or all un-fused, every n_paths a multiple of 64): consecutive offset ranges of the launch, one per call.
 int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
-                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths, RlTraceUnit* const* merged = nullptr,
-                 const uint64_t* first_paths = nullptr, uint32_t n_merged = 0, uint32_t max_blocks = 0) {
+                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths, const MergedJob* merged = nullptr,
+                 uint32_t n_merged = 0, uint32_t max_blocks = 0) {
+    if (n_merged > 1) {
+        n_paths = 0;
+        for (uint32_t k = 0; k < n_merged; ++k) n_paths += merged[k].n_paths;
+        first_path = 0;
+        plot_unit = merged[0].plot; // only selects the fused kernel; the targets come from the job table
+    }
     if (n_paths == 0) return RL_OK;
     if (first_path + n_paths < first_path || first_path + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
@@ -170,16 +183,17 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.first_path = first_path;
     job.n_paths = n_paths;
     job.n_jobs = 1;
-    job.paths_per_job = 0;
+    job.reserved = 0;
     if (n_merged > 1) {
         job.n_jobs = n_merged;
-        job.paths_per_job = u->n_photons;
-        job.n_paths = (uint64_t)n_merged * u->n_photons;
-        n_paths = job.n_paths;
         u->job_host.resize(n_merged);
+        uint64_t start = 0;
         for (uint32_t k = 0; k < n_merged; ++k) {
-            u->job_host[k].photons = merged[k]->photons;
-            u->job_host[k].first_path = first_paths[k];
+            u->job_host[k].target = merged[k].plot ? (void*)merged[k].plot->xyz : (void*)merged[k].unit->photons;
+            u->job_host[k].first_path = merged[k].first_path;
+            u->job_host[k].start = start;
+            start += merged[k].n_paths;
+            u->job_host[k].end = start;
         }
     }
 
@@ -188,10 +202,13 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const size_t blob_bytes = scene->staged_bytes;
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     const bool fused = plot != nullptr;
-    auto kernel = stage ? (fused ? rl_trace_kernel<true, true> : rl_trace_kernel<true, false>)
-                        : (fused ? rl_trace_kernel<false, true> : rl_trace_kernel<false, false>);
+    const bool multi = n_merged > 1;
+    auto kernel = multi ? (stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)
+                                 : (fused ? rl_trace_kernel<false, true, true> : rl_trace_kernel<false, false, true>))
+                        : (stage ? (fused ? rl_trace_kernel<true, true, false> : rl_trace_kernel<true, false, false>)
+                                 : (fused ? rl_trace_kernel<false, true, false> : rl_trace_kernel<false, false, false>));
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
-    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused) { // once per (unit, scene size)
+    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused || u->tuned_multi != multi) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int per_cu = 1;
@@ -200,6 +217,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         u->tuned_dyn = dyn;
         u->tuned_stage = stage;
         u->tuned_fused = fused;
+        u->tuned_multi = multi;
     }
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
@@ -214,15 +232,17 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         RL_HIP(hipEventCreate(&ep.start));
         RL_HIP(hipEventCreate(&ep.stop));
     }
-    if (plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
+    if (n_merged <= 1 && plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
     if (n_merged > 1) {
         RL_HIP(hipMemcpyAsync(u->job_table, u->job_host.data(), n_merged * sizeof(RlJobEntry), hipMemcpyHostToDevice, u->stream));
-        for (uint32_t k = 0; k < n_merged; ++k) // every merged unit's pending plot must have read its photons first
-            if (merged[k] != u) {
-                RL_HIP(hipEventRecord(merged[k]->guard, merged[k]->stream));
-                RL_HIP(hipStreamWaitEvent(u->stream, merged[k]->guard, 0));
+        for (uint32_t k = 0; k < n_merged; ++k) {
+            if (merged[k].plot) RL_HIP(hipStreamWaitEvent(u->stream, merged[k].plot->cleared, 0));
+            if (merged[k].unit != u) { // whatever is queued on that unit's stream (a pending plot reading its photons) first
+                RL_HIP(hipEventRecord(merged[k].unit->guard, merged[k].unit->stream));
+                RL_HIP(hipStreamWaitEvent(u->stream, merged[k].unit->guard, 0));
             }
+        }
     }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
@@ -230,9 +250,11 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
     RL_HIP(hipEventRecord(u->rendered, u->stream));
-    for (uint32_t k = 0; k < n_merged; ++k)
-        if (merged[k] != u) RL_HIP(hipEventRecord(merged[k]->rendered, u->stream));
-    if (plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
+    for (uint32_t k = 0; k < n_merged; ++k) {
+        if (merged[k].unit != u) RL_HIP(hipEventRecord(merged[k].unit->rendered, u->stream));
+        if (n_merged > 1 && merged[k].plot) RL_HIP(hipStreamWaitEvent(merged[k].plot->stream, u->rendered, 0));
+    }
+    if (n_merged <= 1 && plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
     u->pending.push_back(ep);
     u->launches += 1;
     if (u->pending.size() > 512) return drain_events(u);
@@ -435,6 +457,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->tuned_dyn = 0;
     u->tuned_stage = false;
     u->tuned_fused = false;
+    u->tuned_multi = false;
     u->tuned_per_cu = 0;
     u->cu_count = 256;
     hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));
@@ -513,8 +536,9 @@ namespace {
 
 struct RenderCall {
     RlTraceUnit* unit;
+    RlPlotUnit* plot; // fused call: the target; un-fused: nullptr
     const RlScene* scene;
-    uint64_t seed, first_path;
+    uint64_t seed, first_path, n_paths;
     uint32_t stream;
     int rc = RL_OK;
     std::string error;
@@ -539,21 +563,28 @@ DeviceBatcher* batcher_of(int device) {
 bool mergeable(const RenderCall& a, const RenderCall& b) {
     const RlTraceUnit *x = a.unit, *y = b.unit;
     return a.scene == b.scene && a.seed == b.seed && a.stream == b.stream && x->width == y->width && x->height == y->height &&
-           x->n_photons == y->n_photons && x->fetch == y->fetch && x->device == y->device && x != y;
+           x->fetch == y->fetch && x->device == y->device && x != y && (a.plot != nullptr) == (b.plot != nullptr) &&
+           (a.plot == nullptr || a.plot != b.plot) && b.n_paths % 64 == 0 && b.n_paths != 0;
 }
 
 } // namespace
 
-int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
-    if (!u || !scene) return fail(RL_E_INVALID, "null handle");
+namespace {
+
+// The blocking render of both kinds behind the batcher: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
+int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream, uint64_t first_path_index,
+                    uint64_t n_paths) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if (n_paths == 0) return RL_OK;
     DeviceBatcher* b = batcher_of(u->device);
     RenderCall me;
     me.unit = u;
+    me.plot = plot;
     me.scene = scene;
     me.seed = seed;
     me.first_path = first_path_index;
+    me.n_paths = n_paths;
     me.stream = stream;
     std::unique_lock<std::mutex> guard(b->lock);
     b->waiting.push_back(&me);
@@ -576,7 +607,7 @@ int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, ui
         // Lead: my call plus every compatible one waiting right now (merging needs batch sizes the kernel can map
         // back to a job per stash refill: multiples of RL_CHUNK).
         std::vector<RenderCall*> group;
-        const bool can_merge = u->n_photons % (uint32_t)RL_CHUNK == 0;
+        const bool can_merge = n_paths % 64 == 0;
         for (RenderCall* c : b->waiting)
             if (!c->taken && (c == &me || (can_merge && group.size() < RL_MAX_MERGED_JOBS && mergeable(me, *c)))) {
                 c->taken = true;
@@ -592,17 +623,12 @@ int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, ui
         guard.unlock();
         int launch_rc;
         if (group.size() == 1) {
-            launch_rc = launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons, nullptr, nullptr, 0,
+            launch_rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths, nullptr, 0,
                                      max_blocks);
         } else {
-            std::vector<RlTraceUnit*> units;
-            std::vector<uint64_t> firsts;
-            for (RenderCall* c : group) {
-                units.push_back(c->unit);
-                firsts.push_back(c->first_path);
-            }
-            launch_rc = launch_trace(u, scene, nullptr, nullptr, seed, stream, 0, (uint64_t)units.size() * u->n_photons, units.data(),
-                                     firsts.data(), (uint32_t)units.size(), max_blocks);
+            std::vector<MergedJob> jobs;
+            for (RenderCall* c : group) jobs.push_back(MergedJob{c->unit, c->plot, c->first_path, c->n_paths});
+            launch_rc = launch_trace(u, scene, nullptr, nullptr, seed, stream, 0, 0, jobs.data(), (uint32_t)jobs.size(), max_blocks);
         }
         if (launch_rc == RL_OK && hipStreamSynchronize(u->stream) != hipSuccess) launch_rc = fail(RL_E_HIP, "hipStreamSynchronize failed");
         const std::string message = launch_rc == RL_OK ? std::string() : g_error;
@@ -620,6 +646,22 @@ int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, ui
     if (me.rc != RL_OK) return fail(me.rc, me.error);
     return RL_OK;
 }
+
+} // namespace
+
+int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
+    if (!u || !scene) return fail(RL_E_INVALID, "null handle");
+    return render_blocking(u, scene, nullptr, seed, stream, first_path_index, u->n_photons);
+}
+
+int rl_trace_unit_render_fused_sync(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
+                                    uint64_t first_path_index, uint64_t n_paths) {
+    if (!u || !scene || !plot) return fail(RL_E_INVALID, "null handle");
+    if (plot->device != u->device || plot->width != u->width || plot->height != u->height)
+        return fail(RL_E_STATE, "plot unit does not match the trace unit (device or size)");
+    return render_blocking(u, scene, plot, seed, stream, first_path_index, n_paths);
+}
+
 
 int rl_trace_unit_render_fused(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
                                uint64_t first_path_index, uint64_t n_paths) {

@@ -226,15 +226,21 @@ void execute_task(AppState& a, const RlTask& task) {
             if (task.n_units != 0) {
                 const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
                 const uint64_t first = a.fused_next_path.fetch_add(n);
-                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
-                    RlTraceUnit* u = a.ranks[r].trace_units[task.units[0]];
-                    if (c.queued_trace) rc = rl_trace_unit_sync(u); // back-pressure only: this unit's previous launch
-                    if (rc == RL_OK)
-                        rc = rl_trace_unit_render_fused(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed, c.stream + (uint32_t)r,
-                                                        first, n);
+                if (!c.queued_trace && a.ranks.size() == 1) {
+                    // the blocking call: Plot tasks of concurrent workers share one launch (and one drain tail)
+                    rc = rl_trace_unit_render_fused_sync(a.ranks[0].trace_units[task.units[0]], a.ranks[0].scene, a.ranks[0].plot_units[task.unit],
+                                                         c.seed, c.stream, first, n);
+                } else {
+                    for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
+                        RlTraceUnit* u = a.ranks[r].trace_units[task.units[0]];
+                        if (c.queued_trace) rc = rl_trace_unit_sync(u); // back-pressure only: this unit's previous launch
+                        if (rc == RL_OK)
+                            rc = rl_trace_unit_render_fused(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
+                                                            c.stream + (uint32_t)r, first, n);
+                    }
+                    if (!c.queued_trace)
+                        for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
                 }
-                if (!c.queued_trace)
-                    for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
             }
         }
         break;

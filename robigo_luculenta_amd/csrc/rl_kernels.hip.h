@@ -43,15 +43,17 @@ struct RlTraceJob {
     uint64_t seed;
     uint64_t first_path;     // single job: path index of offset 0
     uint64_t n_paths;        // all jobs together
-    uint32_t n_jobs;         // > 1: a merged launch of several TraceUnit::render calls (rl_api.hip's batcher)
-    uint32_t paths_per_job;  // a multiple of RL_CHUNK, so the 64 offsets of a stash refill belong to one job
+    uint32_t n_jobs;         // > 1: a merged launch of several render calls (rl_api.hip's batcher)
+    uint32_t reserved;
 };
 
-// One TraceUnit::render of a merged launch: offsets [k * paths_per_job, (k + 1) * paths_per_job) of the launch are
-// path indices first_path .. of this job and fill this unit's mapped_photons.
+// One call of a merged launch: offsets [start, end) of the launch are the path indices first_path .. of this call
+// and go to `target` (un-fused: the unit's mapped_photons; fused: the plot unit's tristimulus buffer).  start and
+// end are multiples of 64, so the 64 offsets of a stash refill always belong to one call.
 struct RlJobEntry {
-    RlMappedPhoton* photons;
+    void* target;
     uint64_t first_path;
+    uint64_t start, end;
 };
 
 // Diagnostic build only (make stats): wave-level event counters of the trace kernel, read back by
@@ -457,7 +459,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // FUSED: paths that end on a light are splatted into `plot` (photons unused); otherwise every path's
 // MappedPhoton goes to `photons` (plot unused).  A compile-time switch so neither variant carries the
 // other's code and registers.
-template <bool STAGE_LDS, bool FUSED>
+// MULTI: the launch carries several render calls (job table); a compile-time switch so that a single call's launch
+// -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
+template <bool STAGE_LDS, bool FUSED, bool MULTI>
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                                   RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                                   float* __restrict__ plot,
@@ -533,13 +537,16 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
         if (lane < count) {
             const uint32_t slot = (e_head + lane) & 127u;
             const float sx = emit[0 * 128 + slot], sy = emit[1 * 128 + slot], wavelength = emit[2 * 128 + slot];
-            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, rl_f2u(emit[4 * 128 + slot]));
+            const uint32_t tagged = rl_f2u(emit[4 * 128 + slot]);
+            float* target = plot;
+            if (MULTI) target = (float*)jobs[tagged >> 24].target;
+            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, MULTI ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
                 const RlSplat sp = rl_splat_weights(job.width, job.height, job.aspect_ratio, sx, sy);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float* px = plot + 3ull * sp.idx[k];
+                    float* px = target + 3ull * sp.idx[k];
                     unsafeAtomicAdd(px + 0, cie.x * sp.w[k]);
                     unsafeAtomicAdd(px + 1, cie.y * sp.w[k]);
                     unsafeAtomicAdd(px + 2, cie.z * sp.w[k]);
@@ -573,10 +580,9 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     chunk_end = chunk_next + chunk;
                 }
                 RL_STAT(RL_ST_REFILLS, 1);
-                if (!FUSED && job.n_jobs > 1) { // all 64 offsets of a refill lie in one job (paths_per_job % RL_CHUNK == 0)
-                    const uint32_t j = (uint32_t)(chunk_next / job.paths_per_job);
-                    stash_job = j < job.n_jobs ? j : job.n_jobs - 1u;
-                    stash_first = jobs[stash_job].first_path - (uint64_t)stash_job * job.paths_per_job;
+                if (MULTI) { // all 64 offsets of a refill lie in one call; a wave's offsets only grow
+                    while (stash_job + 1u < job.n_jobs && chunk_next >= jobs[stash_job].end) stash_job += 1u;
+                    stash_first = jobs[stash_job].first_path - jobs[stash_job].start;
                 }
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 const uint32_t lo = stash_off[slot], hi = stash_off[64 + slot];
                 if ((lo & hi) != 0xffffffffu) {
                     my_path = ((uint64_t)hi << 32) | lo;
-                    my_job = stash_job;
+                    if (MULTI) my_job = stash_job;
                     p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
                     p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
                     p.wavelength = stash[6 * 64 + slot];
@@ -673,15 +679,15 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     ph.y = p.sy;
                     ph.probability = value;
                     ph.wavelength = p.wavelength;
-                    if (job.n_jobs > 1) {
+                    if (MULTI) {
                         const RlJobEntry e = jobs[my_job];
-                        e.photons[my_path - e.first_path] = ph;
+                        ((RlMappedPhoton*)e.target)[my_path - e.first_path] = ph;
                     } else {
                         photons[my_path - job.first_path] = ph;
                     }
                 } else {
                     ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
-                    emit_obj = emitter;
+                    emit_obj = MULTI ? (emitter | (my_job << 24)) : emitter; // merged launches: the call, i.e. the plot buffer
                 }
             }
         }

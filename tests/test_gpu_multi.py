@@ -256,3 +256,41 @@ def test_concurrent_renders_are_merged_into_one_launch_and_stay_bit_exact(R):
         launches = sum(1 for s in stats if s[2] > 0)
         if n % 256 == 0:
             assert launches <= workers        # merged launches are accounted to the unit that led them
+
+
+def test_concurrent_fused_renders_share_a_launch_and_hit_their_own_plot_units(R):
+    """rl_trace_unit_render_fused_sync from several threads: one launch splats into every caller's plot unit
+    (job table in the kernel); each buffer must equal the oracle's plot of that caller's path range."""
+    import threading
+    W, H, workers = 96, 54, 6
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    sizes = [1 << 13, 3 << 12, 1 << 13, 5 << 11, 1 << 12, 1000]       # the last is not a multiple of 64: launched alone
+    units = [R.TraceUnit(i, W, H, n_photons=64) for i in range(workers)]
+    plots = [R.PlotUnit(i, W, H) for i in range(workers)]
+    firsts = [100000 * (workers - i) + 17 for i in range(workers)]
+    start = threading.Barrier(workers)
+    before = R.batch_histogram()
+    errors = []
+
+    def work(i):
+        try:
+            start.wait()
+            units[i].render_fused_sync(scene, plots[i], sizes[i], seed=8, stream=1, first_path_index=firsts[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    segs = 0
+    for i in range(workers):
+        photons, s = oscene.render(W, H, 8, 1, firsts[i], sizes[i], threads=4)
+        segs += s
+        want = O.plot(W, H, photons)
+        assert np.allclose(plots[i].tristimulus_buffer, want, rtol=2e-5, atol=1e-7), i
+    assert sum(u.stats()[1] for u in units) == segs and sum(u.stats()[0] for u in units) == sum(sizes)
+    after = R.batch_histogram()
+    assert sum(k * (after.get(k, 0) - before.get(k, 0)) for k in after) == workers      # every call went through the batcher
