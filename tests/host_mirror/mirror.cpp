@@ -139,3 +139,19 @@ extern "C" uint32_t mirror_bounds(void* scene, float* out4, uint32_t cap, uint32
     for (size_t i = 0; i < fs.prisms.size() / RL_PRISM_STRIDE; ++i) put(fs.prisms[RL_PRISM_STRIDE * i + 16]);
     return n;
 }
+
+// The second level of the cull table: one bound {centre, radius^2} per RL_GROUP_G consecutive level-1 bounds
+// (reconstructed from the {c, |c|^2 - R^2} records the kernel reads).  Returns the number of groups.
+extern "C" uint32_t mirror_group_bounds(void* scene, float* out4, uint32_t cap, uint32_t* group_size) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    const uint32_t n_level1 = RL_GROUP_G * (fs.n_cluster_groups + fs.n_prism_groups);
+    const uint32_t n_groups = fs.n_cluster_groups + fs.n_prism_groups;
+    if (group_size) *group_size = RL_GROUP_G;
+    for (uint32_t g = 0; g < n_groups && g < cap; ++g) {
+        const RlF4 r = fs.cull_bounds[n_level1 + g];
+        const double c2 = (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z;
+        out4[4 * g] = r.x; out4[4 * g + 1] = r.y; out4[4 * g + 2] = r.z;
+        out4[4 * g + 3] = (float)(c2 - (double)r.w);
+    }
+    return n_groups;
+}

@@ -107,3 +107,51 @@ def test_degenerate_scenes_bit_exact():
         assert got.tobytes() == want.tobytes()
         if len(objs) == 0:
             assert segs == 1 << 11 and not want["probability"].any()
+
+
+def test_cull_table_is_conservative_by_construction():
+    """The kernel's two-level cull table (rl_scene.cpp; not in the reference): every sphere lies inside its cluster's
+    bounding sphere, every cluster / prism bound inside its group's -- so a ray that misses a bound cannot hit
+    anything below it, whatever the parity sweeps happen to sample.  Checked in f64 on the built-in and on random
+    scenes; the padding entries can never be reached (radius^2 = -inf)."""
+    import ctypes as C
+    from _random_scene import random_scene
+    L = M.lib()
+    L.mirror_bounds.restype = C.c_uint32
+    L.mirror_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mirror_group_bounds.restype = C.c_uint32
+    L.mirror_group_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    scenes = [M.builtin_desc(0, 0), M.builtin_desc(1, 0), M.builtin_desc(0, 158)]
+    scenes += [random_scene(seed, n_spheres=90 + 37 * seed, n_prisms=3 + 2 * seed) for seed in range(4)]
+    checked = 0
+    for objs, cam in scenes:
+        sc = M.Scene(objs, cam)
+        b = np.zeros((2048, 4), np.float32)
+        nc = C.c_uint32(0)
+        nb = L.mirror_bounds(sc.h, O.ptr(b), len(b), C.byref(nc))
+        b = b[:nb].astype(np.float64)
+        g = np.zeros((1024, 4), np.float32)
+        G = C.c_uint32(0)
+        ng = L.mirror_group_bounds(sc.h, O.ptr(g), len(g), C.byref(G))
+        g, G = g[:ng].astype(np.float64), G.value
+        assert nb == ng * G and nc.value % G == 0
+        for k in range(ng):
+            members = b[G * k: G * k + G]
+            real = members[np.isfinite(members[:, 3]) & (members[:, 3] > 0)]
+            assert len(real) >= 1                                  # a group is never all padding
+            if not np.isfinite(g[k, 3]):
+                continue                                           # unbounded group: always reached
+            reach = np.sqrt(((real[:, :3] - g[k, :3]) ** 2).sum(1)) + np.sqrt(real[:, 3])
+            assert (reach <= np.sqrt(g[k, 3]) * (1 + 1e-6)).all(), (k, reach, g[k])
+            checked += len(real)
+        # level 1 over the spheres: every clustered sphere inside its cluster bound (5 % + 0.05 inflation)
+        spheres = objs[objs["surface_kind"] == 0]
+        centres, radii = spheres["v0"].astype(np.float64), np.abs(spheres["f"][:, 0].astype(np.float64))
+        if nc.value:
+            clusters = b[: nc.value]
+            clusters = clusters[np.isfinite(clusters[:, 3]) & (clusters[:, 3] > 0)]
+            d = np.sqrt(((centres[:, None, :] - clusters[None, :, :3]) ** 2).sum(-1)) + radii[:, None]
+            inside_some = (d <= np.sqrt(clusters[None, :, 3])).any(1)
+            big = radii > 4 * np.median(radii)                     # the direct list
+            assert inside_some[~big].all()
+    assert checked > 150
