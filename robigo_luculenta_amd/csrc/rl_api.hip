@@ -642,6 +642,7 @@ int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint
         b->changed.notify_all();
     }
     b->callers -= 1;
+    if (b->callers == 0 && b->peak_callers > 1) b->peak_callers -= 1; // forget a host that has fewer workers now
     guard.unlock();
     if (me.rc != RL_OK) return fail(me.rc, me.error);
     return RL_OK;

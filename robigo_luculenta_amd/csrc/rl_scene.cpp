@@ -499,6 +499,10 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         *err = "null scene description";
         return RL_E_INVALID;
     }
+    if (desc->n_objects > (1u << 24)) { // object indices travel in 24-bit fields (merge keys, the emitter queue's tag)
+        *err = "more than 2^24 objects";
+        return RL_E_INVALID;
+    }
     RlFlatScene& fs = *out;
     fs = RlFlatScene();
     std::vector<SphereIn> sph_in;
