@@ -369,8 +369,8 @@ int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
  * 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette decision (trace_unit.rs:122-125) for the triples
  * (x[i], x[m+i], x[2m+i]) = (rand, continue_chance, intensity), i < m = n / 3, result 1 or 0 in y[i]. */
 int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
-/* Concurrent rl_trace_unit_render calls are merged into one launch (see rl_trace_unit_render).  out[k], k = 1..64:
- * launches on `device` that carried k calls since the library was loaded (65 counters, out[0] unused). */
+/* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
+ * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
 int rl_debug_batch_histogram(int device, uint64_t* out);
 
 #ifdef __cplusplus

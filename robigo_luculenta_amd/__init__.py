@@ -363,9 +363,9 @@ def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_bat
 
 def batch_histogram(device=0):
     """{k: launches that carried k merged TraceUnit.render calls} since the library was loaded."""
-    out = (C.c_uint64 * 65)()
+    out = (C.c_uint64 * 257)()
     check(lib.rl_debug_batch_histogram(device, out))
-    return {k: int(out[k]) for k in range(1, 65) if out[k]}
+    return {k: int(out[k]) for k in range(1, 257) if out[k]}
 
 
 def math_probe(fn, x, device=0):

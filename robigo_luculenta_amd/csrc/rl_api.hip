@@ -25,6 +25,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <rccl/rccl.h> // types and prototypes only: the library is bound at run time (rccl_api below)
@@ -96,6 +97,7 @@ struct RlTraceUnit {
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
     bool tuned_stage, tuned_fused, tuned_multi; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
+    uint64_t session_paths = 0, session_segments = 0; // of this unit's calls that open launches served
 };
 
 struct RlPlotUnit {
@@ -203,10 +205,10 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     const bool fused = plot != nullptr;
     const bool multi = n_merged > 1;
-    auto kernel = multi ? (stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)
-                                 : (fused ? rl_trace_kernel<false, true, true> : rl_trace_kernel<false, false, true>))
-                        : (stage ? (fused ? rl_trace_kernel<true, true, false> : rl_trace_kernel<true, false, false>)
-                                 : (fused ? rl_trace_kernel<false, true, false> : rl_trace_kernel<false, false, false>));
+    auto kernel = multi ? (stage ? (fused ? rl_trace_kernel<true, true, true, false> : rl_trace_kernel<true, false, true, false>)
+                                 : (fused ? rl_trace_kernel<false, true, true, false> : rl_trace_kernel<false, false, true, false>))
+                        : (stage ? (fused ? rl_trace_kernel<true, true, false, false> : rl_trace_kernel<true, false, false, false>)
+                                 : (fused ? rl_trace_kernel<false, true, false, false> : rl_trace_kernel<false, false, false, false>));
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
     if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused || u->tuned_multi != multi) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
@@ -223,6 +225,8 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
     if (max_blocks != 0 && blocks > max_blocks) blocks = max_blocks; // this launch's share of the CUs (the batcher)
+    static const uint64_t env_blocks = getenv("RL_TRACE_MAX_BLOCKS") ? (uint64_t)atoll(getenv("RL_TRACE_MAX_BLOCKS")) : 0; // experiments
+    if (env_blocks != 0 && blocks > env_blocks) blocks = env_blocks;
 
     EventPair ep;
     if (!u->pool.empty()) {
@@ -246,7 +250,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
-                       plot, u->queue, (const RlJobEntry*)u->job_table);
+                       plot, u->queue, (const RlJobEntry*)u->job_table, (RlOpenDev*)nullptr, (RlOpenCtl*)nullptr);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
     RL_HIP(hipEventRecord(u->rendered, u->stream));
@@ -422,9 +426,14 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     return RL_OK;
 }
 
+namespace {
+int sessions_quiesce(int device, double* ms);
+}
+
 int rl_scene_destroy(RlScene* scene) {
     if (!scene) return RL_OK;
     (void)hipSetDevice(scene->device);
+    (void)sessions_quiesce(scene->device, nullptr); // an open launch may still be reading the blob
     (void)hipFree(scene->blob);
     delete scene;
     return RL_OK;
@@ -571,12 +580,292 @@ bool mergeable(const RenderCall& a, const RenderCall& b) {
 
 namespace {
 
+// ---- sessions: open launches (rl_kernels.hip.h, RlOpenDev / RlOpenCtl) ---------------------------------------------
+// Blocking render calls of at most RL_SESSION_MAX_PATHS paths are APPENDED to a trace kernel that is already running
+// on the device whenever there is one that still accepts work (same scene, seed, stream, image size, fetch mode,
+// fused or not); otherwise the call starts such a kernel with itself as the first job.  Each call returns as soon as
+// ITS paths are finished -- the kernel goes on with the other callers' -- so the drain tail of one 524,288-path batch
+// overlaps the next batches instead of idling the chip, and nothing is launched per call.  A kernel closes itself the
+// moment a wave finds nothing left to hand out; a call that arrives too late for it starts the next one, whose
+// workgroups move onto the CUs as the closed one's drain.
+
+struct Session {
+    hipStream_t stream = nullptr;
+    RlOpenDev* od = nullptr;
+    RlOpenCtl* ctl = nullptr;     // pinned, coherent host memory
+    RlOpenCtl* ctl_dev = nullptr; // the same memory as the device addresses it
+    unsigned long long* counters = nullptr; // [unused, segments, paths] of the running kernel
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool launched = false; // a kernel was launched and its counters are not harvested yet
+    bool open = false;     // the host may still try to append
+    uint32_t n = 0;        // jobs appended so far
+    int waiters = 0;       // calls that have not yet read their completion flag (ctl must not be recycled under them)
+    const RlScene* scene = nullptr;
+    uint64_t seed = 0;
+    uint32_t stream_id = 0, width = 0, height = 0;
+    int fetch = 0;
+    bool fused = false;
+};
+
+struct DeviceSessions {
+    std::mutex lock;
+    std::condition_variable changed;
+    Session s[4];
+    bool ready = false;
+    uint64_t launches = 0;
+    double kernel_ms = 0.0; // of finished kernels, not yet credited to a trace unit (rl_trace_unit_stats)
+    uint64_t histogram[RL_OPEN_CAP + 1] = {}; // finished kernels by number of calls they carried
+    double presync_us = 0.0, admit_us = 0.0, wait_us = 0.0; // where the calls spent their time (RL_SESSION_TIMING=1 prints it)
+    uint64_t calls = 0, starts = 0;
+};
+
+DeviceSessions* sessions_of(int device) {
+    static DeviceSessions all[64];
+    return &all[device >= 0 && device < 64 ? device : 0];
+}
+
+bool sessions_enabled() {
+    static const bool on = !(getenv("RL_SESSIONS") && atoi(getenv("RL_SESSIONS")) == 0);
+    return on;
+}
+
+inline uint32_t host_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+
+int sessions_setup(DeviceSessions* d) { // under d->lock, device current
+    if (d->ready) return RL_OK;
+    int least = 0, greatest = 0;
+    RL_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (Session& x : d->s) {
+        // a priority of its own = a hardware queue of its own: the streams of the plot / gather / tonemap kernels must
+        // never queue up behind a resident trace kernel (they run beside it in the registers it leaves free)
+        const char* how = getenv("RL_SESSION_STREAM"); // experiment
+        if (how && !strcmp(how, "high")) RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, greatest));
+        else if (how && !strcmp(how, "normal")) RL_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+        else if (how && !strcmp(how, "cumask")) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
+            RL_HIP(hipExtStreamCreateWithCUMask(&x.stream, 8, mask));
+        } else RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, least));
+        if (getenv("RL_SESSION_TIMING")) fprintf(stderr, "stream priority range: least %d greatest %d\n", least, greatest);
+        RL_HIP(hipMalloc((void**)&x.od, sizeof(RlOpenDev)));
+        RL_HIP(hipHostMalloc((void**)&x.ctl, sizeof(RlOpenCtl), hipHostMallocCoherent | hipHostMallocMapped));
+        RL_HIP(hipHostGetDevicePointer((void**)&x.ctl_dev, x.ctl, 0));
+        RL_HIP(hipMalloc((void**)&x.counters, 3 * sizeof(unsigned long long)));
+        RL_HIP(hipEventCreate(&x.start));
+        RL_HIP(hipEventCreate(&x.stop));
+    }
+    d->ready = true;
+    return RL_OK;
+}
+
+// The kernel of session x has ended (or was never launched): add its counters to the device's tally.
+int session_harvest(DeviceSessions* d, Session& x) {
+    if (!x.launched) return RL_OK;
+    RL_HIP(hipStreamSynchronize(x.stream));
+    float ms = 0.0f;
+    RL_HIP(hipEventElapsedTime(&ms, x.start, x.stop));
+    d->kernel_ms += (double)ms;
+    d->launches += 1;
+    const uint32_t carried = host_load(&x.ctl->final_at);
+    d->histogram[carried <= RL_OPEN_CAP ? carried : 0] += 1;
+    x.launched = false;
+    x.open = false;
+    return RL_OK;
+}
+
+// Waits until no session kernel runs on `device`; their kernel time not yet credited to a unit is added to *ms.
+int sessions_quiesce(int device, double* ms) {
+    DeviceSessions* d = sessions_of(device);
+    std::lock_guard<std::mutex> guard(d->lock);
+    if (!d->ready) return RL_OK;
+    for (Session& x : d->s) {
+        const int rc = session_harvest(d, x);
+        if (rc != RL_OK) return rc;
+    }
+    if (ms) *ms += d->kernel_ms, d->kernel_ms = 0.0;
+    return RL_OK;
+}
+
+int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* scene, bool fused, uint64_t seed, uint32_t stream_id,
+                  const RlJobEntry& first) {
+    int rc = session_harvest(d, x);
+    if (rc != RL_OK) return rc;
+    x.scene = scene;
+    x.seed = seed;
+    x.stream_id = stream_id;
+    x.width = u->width;
+    x.height = u->height;
+    x.fetch = u->fetch;
+    x.fused = fused;
+    RlTraceJob job;
+    job.width = u->width;
+    job.height = u->height;
+    job.aspect_ratio = (float)u->width / (float)u->height;
+    job.stream = stream_id;
+    job.seed = seed;
+    job.first_path = 0;
+    job.n_paths = 0;
+    job.n_jobs = 0;
+    static const uint32_t grace_us = getenv("RL_SESSION_GRACE_US") ? (uint32_t)atoi(getenv("RL_SESSION_GRACE_US")) : 150u;
+    job.reserved = grace_us * 100u; // ticks of wall_clock64() (100 MHz) an idle open launch waits for another call
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
+    const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
+    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true, true> : rl_trace_kernel<true, false, true, true>)
+                        : (fused ? rl_trace_kernel<false, true, true, true> : rl_trace_kernel<false, false, true, true>);
+    const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
+    RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int per_cu = 1;
+    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
+    if (per_cu < 1) per_cu = 1;
+    std::memset(x.ctl, 0, sizeof(RlOpenCtl));
+    x.ctl->jobs[0] = first;
+    x.ctl->closed_at = RL_OPEN_NONE;
+    x.ctl->final_at = RL_OPEN_NONE;
+    __atomic_store_n(&x.ctl->published, 1u, __ATOMIC_SEQ_CST);
+    x.n = 1;
+    RL_HIP(hipMemsetAsync(x.od, 0, sizeof(RlOpenDev), x.stream));
+    RL_HIP(hipMemsetAsync(x.counters, 0, 3 * sizeof(unsigned long long), x.stream));
+    RL_HIP(hipEventRecord(x.start, x.stream));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(u->cu_count * per_cu)), dim3(RL_TRACE_BLOCK), dyn, x.stream, scene->blob, scene->lay, job,
+                       (RlMappedPhoton*)nullptr, (float*)nullptr, x.counters, (const RlJobEntry*)x.od->jobs, x.od, x.ctl_dev);
+    RL_HIP(hipGetLastError());
+    RL_HIP(hipEventRecord(x.stop, x.stream));
+    x.launched = true;
+    x.open = true;
+    return RL_OK;
+}
+
+// Appends `e` to the running kernel of x.  Returns the job index, or -1 when the kernel had already closed.
+int session_append(Session& x, const RlJobEntry& e) {
+    const uint32_t k = x.n;
+    x.ctl->jobs[k] = e;
+    __atomic_store_n(&x.ctl->done[k], 0u, __ATOMIC_RELAXED);
+    __atomic_store_n(&x.ctl->published, k + 1u, __ATOMIC_SEQ_CST);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    for (uint64_t spins = 0;; ++spins) {
+        const uint32_t closed_at = host_load(&x.ctl->closed_at);
+        if (closed_at == RL_OPEN_NONE || closed_at > k) break; // it had not closed when the entry became visible, or re-opened
+        const uint32_t final_at = host_load(&x.ctl->final_at);
+        if (final_at != RL_OPEN_NONE && final_at <= k) return -1;
+        if (spins > 1000000 && hipStreamQuery(x.stream) != hipErrorNotReady) return -1; // the kernel is gone (an error surfaces later)
+        __builtin_ia32_pause();
+    }
+    x.n = k + 1u;
+    return (int)k;
+}
+
+// Blocks until job k of session x is complete.
+int session_wait(Session& x, uint32_t k) {
+    auto last_query = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        if (host_load(&x.ctl->done[k]) != 0u) return RL_OK;
+        if (spins < 4000) {
+            __builtin_ia32_pause();
+        } else if ((spins & 255u) == 0u && std::chrono::steady_clock::now() - last_query > std::chrono::milliseconds(20)) {
+            // rarely (the query is not cheap while a kernel runs): has the kernel died or ended under the call?
+            last_query = std::chrono::steady_clock::now();
+            const hipError_t q = hipStreamQuery(x.stream);
+            if (q == hipSuccess) { // the kernel has ended: it reported every accepted job before that
+                if (host_load(&x.ctl->done[k]) != 0u) return RL_OK;
+                return fail(RL_E_STATE, "an open trace launch ended without completing one of its calls");
+            }
+            if (q != hipErrorNotReady) return fail(RL_E_HIP, std::string("open trace launch: ") + hipGetErrorString(q));
+        } else {
+            std::this_thread::yield();
+        }
+    }
+}
+
+int render_session(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream_id, uint64_t first_path_index,
+                   uint64_t n_paths) {
+    // What the call's target is still being read or cleared by (a plot of the unit's previous photons, the gather's
+    // clear of the plot buffer) must be over before a kernel that is already running may write to it.
+    const auto t0 = std::chrono::steady_clock::now();
+    if (plot) RL_HIP(hipEventSynchronize(plot->cleared));
+    else RL_HIP(hipStreamSynchronize(u->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    RlJobEntry e;
+    e.target = plot ? (void*)plot->xyz : (void*)u->photons;
+    e.first_path = first_path_index;
+    e.start = 0;
+    e.end = n_paths;
+    DeviceSessions* d = sessions_of(u->device);
+    Session* mine = nullptr;
+    int k = -1;
+    {
+        std::unique_lock<std::mutex> guard(d->lock);
+        int rc = sessions_setup(d);
+        if (rc != RL_OK) return rc;
+        for (;;) {
+            for (Session& x : d->s) // a running kernel that takes this call?
+                if (x.open && x.n < RL_OPEN_CAP && x.scene == scene && x.seed == seed && x.stream_id == stream_id && x.width == u->width &&
+                    x.height == u->height && x.fetch == u->fetch && x.fused == (plot != nullptr)) {
+                    k = session_append(x, e);
+                    if (k >= 0) mine = &x, x.waiters += 1;
+                    else x.open = false;
+                    break;
+                }
+            if (mine) break;
+            for (Session& x : d->s) // a kernel closes itself; the host learns of it here (or when an append is turned down)
+                if (x.open && host_load(&x.ctl->final_at) != RL_OPEN_NONE) x.open = false;
+            for (Session& x : d->s) // no: start one in a slot whose kernel has ended
+                if (!x.open && x.waiters == 0 && (!x.launched || hipStreamQuery(x.stream) == hipSuccess)) {
+                    rc = session_start(d, x, u, scene, plot != nullptr, seed, stream_id, e);
+                    if (rc != RL_OK) return rc;
+                    mine = &x;
+                    x.waiters += 1;
+                    k = 0;
+                    break;
+                }
+            if (mine) break;
+            bool retry = false; // an open session that is full or serves other parameters: close it to the host
+            for (Session& x : d->s)
+                if (x.open && x.n >= RL_OPEN_CAP) x.open = false, retry = true;
+            if (!retry) d->changed.wait_for(guard, std::chrono::microseconds(50));
+        }
+    }
+#ifdef RL_OPEN_DEBUG
+    const auto t_app = std::chrono::steady_clock::now();
+#endif
+    const auto t2 = std::chrono::steady_clock::now();
+    int rc = session_wait(*mine, (uint32_t)k);
+#ifdef RL_OPEN_DEBUG
+    {
+        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_app).count();
+        const RlOpenCtl* c = mine->ctl;
+        if (k >= 100 && k < 140)
+            fprintf(stderr, "job %d: host append->done %.0f us | gpu (us since job 100 known): known %.1f first %.1f last %.1f done %.1f\n", k, host_us,
+                    (double)(long long)(c->t_known[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_first[k] - c->t_known[100]) / 100.0,
+                    (double)(long long)(c->t_last[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_done[k] - c->t_known[100]) / 100.0);
+    }
+#endif
+    const uint64_t job_segments = host_load(&mine->ctl->segs[k]);
+    {
+        const auto t3 = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> guard(d->lock);
+        mine->waiters -= 1;
+        d->presync_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        d->admit_us += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        d->wait_us += std::chrono::duration<double, std::micro>(t3 - t2).count();
+        d->calls += 1;
+    }
+    if (rc != RL_OK) return rc;
+    u->session_paths += n_paths;
+    u->session_segments += job_segments;
+    if (!plot) RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
+    return RL_OK;
+}
+
+#define RL_SESSION_MAX_PATHS (1ull << 28) // per call: its segment count must fit 32 bits
+
 // The blocking render of both kinds behind the batcher: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
 int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream, uint64_t first_path_index,
                     uint64_t n_paths) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
     if (n_paths == 0) return RL_OK;
+    if (sessions_enabled() && n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS)
+        return render_session(u, scene, plot, seed, stream, first_path_index, n_paths);
     DeviceBatcher* b = batcher_of(u->device);
     RenderCall me;
     me.unit = u;
@@ -699,8 +988,11 @@ int rl_trace_unit_stats(RlTraceUnit* u, uint64_t* paths, uint64_t* segments, dou
     if ((rc = drain_events(u)) != RL_OK) return rc;
     unsigned long long q[3];
     RL_HIP(hipMemcpy(q, u->queue, sizeof q, hipMemcpyDeviceToHost));
-    if (segments) *segments = q[1];
-    if (paths) *paths = q[2];
+    // Calls served by open launches are counted per call (session_*); the kernel time of those launches, which serve
+    // many units at once, is credited to whichever unit asks first.
+    if ((rc = sessions_quiesce(u->device, &u->kernel_ms)) != RL_OK) return rc;
+    if (segments) *segments = q[1] + u->session_segments;
+    if (paths) *paths = q[2] + u->session_paths;
     if (kernel_ms) *kernel_ms = u->kernel_ms;
     return RL_OK;
 }
@@ -1225,13 +1517,27 @@ int rl_gather_unit_allreduce(RlGatherUnit* gather, RlPlotUnit* plot, RlComm* com
     return rl_plot_unit_clear(plot);
 }
 
-// Diagnostics: how many launches carried k merged TraceUnit::render calls (k = 1 .. RL_MAX_MERGED_JOBS) on
-// `device` since the library was loaded; out holds RL_MAX_MERGED_JOBS + 1 = 65 counters.
+// Diagnostics: how many launches carried k blocking render calls (k = 1 .. 256) on `device` since the library was
+// loaded; out holds 257 counters.
 int rl_debug_batch_histogram(int device, uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
-    DeviceBatcher* b = batcher_of(device);
-    std::lock_guard<std::mutex> guard(b->lock);
-    for (int k = 0; k <= RL_MAX_MERGED_JOBS; ++k) out[k] = b->histogram[k];
+    for (uint32_t k = 0; k <= RL_OPEN_CAP; ++k) out[k] = 0;
+    {
+        DeviceBatcher* b = batcher_of(device);
+        std::lock_guard<std::mutex> guard(b->lock);
+        for (int k = 0; k <= RL_MAX_MERGED_JOBS; ++k) out[k] = b->histogram[k];
+    }
+    int rc = use_device(device);
+    if (rc == RL_OK) rc = sessions_quiesce(device, nullptr); // the open launches still running end first: then they are counted
+    if (rc != RL_OK) return rc;
+    DeviceSessions* d = sessions_of(device);
+    std::lock_guard<std::mutex> guard(d->lock);
+    for (uint32_t k = 0; k <= RL_OPEN_CAP; ++k) out[k] += d->histogram[k];
+    if (getenv("RL_SESSION_TIMING") && d->calls)
+        fprintf(stderr, "open launches on device %d: %llu calls, mean us per call: wait for the target %.1f, admission %.1f, completion %.1f\n",
+                device, (unsigned long long)d->calls, d->presync_us / d->calls, d->admit_us / d->calls, d->wait_us / d->calls);
+    d->presync_us = d->admit_us = d->wait_us = 0.0;
+    d->calls = 0;
     return RL_OK;
 }
 

@@ -56,6 +56,49 @@ struct RlJobEntry {
     uint64_t start, end;
 };
 
+// ---- open launches ("sessions", rl_api.hip) -------------------------------------------------------
+// A trace kernel that stays resident while the host keeps appending render calls to it: the reference's workers
+// call TraceUnit::render for 524,288 paths at a time (trace_unit.rs:67) -- 0.15 ms of this chip's work followed by
+// ~0.2 ms of waiting for the batch's longest paths -- so instead of one launch per call (or per group of calls
+// that happen to wait at the same moment) the waves of ONE launch take the calls' paths from a job table that
+// grows while they run, and every call is signalled complete on its own as soon as its last path has ended.
+// Host <-> kernel protocol (RlOpenCtl lives in pinned, coherent host memory; RlOpenDev in device memory):
+//   host:    writes ctl->jobs[k], then published = k + 1 (seq_cst), then reads closed_at.
+//   kernel:  a wave that finds every known job handed out takes the `closing` lock, copies newly published
+//            entries into dev->jobs and raises dev->known; if there are none it writes closed_at = known, fences,
+//            re-reads published: unchanged -> final_at = known, dev->closed = 1 (the launch drains and ends);
+//            changed -> closed_at = NONE (re-opened).
+//   host:    job k is accepted iff it reads closed_at == NONE or closed_at > k; rejected (start a new launch) iff
+//            final_at <= k; anything else is the kernel between its two steps: read again.
+//   Both sides write-then-read with sequentially consistent fences, so at least one sees the other (Dekker).
+//   Completion: waves count the paths of job j they finished in dev->fin[j] (a release at agent scope first, so the
+//   photons / splats are visible to later kernels); whoever brings it to the job's size sets ctl->done[j].
+#define RL_OPEN_CAP 256u
+#define RL_OPEN_NONE 0xffffffffu
+struct RlOpenDev {
+    uint32_t known;   // entries [0, known) of jobs[] are valid
+    uint32_t closed;  // no further jobs will be accepted
+    uint32_t pad0[30]; // (polled by waves that are out of work: a cache line of their own)
+    uint32_t closing; // lock: one wave at a time talks to the host
+    uint32_t completed; // jobs whose last path has finished
+    unsigned long long idle_since;  // wall_clock64() when a wave first found every job complete and nothing new (0: not idle)
+    unsigned long long stuck_since; // ... when a wave first found nothing to hand out while calls were still finishing
+    uint32_t pad1[26];
+    uint32_t next[RL_OPEN_CAP]; // per job: next path offset to hand out
+    uint32_t fin[RL_OPEN_CAP];  // per job: paths finished
+    uint32_t seg[RL_OPEN_CAP];  // per job: segments (Scene::intersect calls) of its finished paths
+    RlJobEntry jobs[RL_OPEN_CAP]; // start = 0, end = number of paths
+};
+struct RlOpenCtl {
+    uint32_t published, closed_at, final_at, pad;
+    uint32_t done[RL_OPEN_CAP];
+    uint32_t segs[RL_OPEN_CAP]; // valid once done[j] is set
+    RlJobEntry jobs[RL_OPEN_CAP];
+#ifdef RL_OPEN_DEBUG
+    unsigned long long t_known[RL_OPEN_CAP], t_first[RL_OPEN_CAP], t_last[RL_OPEN_CAP], t_done[RL_OPEN_CAP];
+#endif
+};
+
 // Diagnostic build only (make stats): wave-level event counters of the trace kernel, read back by
 // tools/kernel_stats.py.  RL_STAT(k, v) adds v to counter k once per wave (lane 0).
 #ifdef RL_STATS
@@ -151,6 +194,15 @@ struct RlWaveScratch {
     // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
     // until 64 of them can be evaluated and splatted with a full exec mask.
     float emit[5][128];
+};
+
+// Open launches: per-workgroup LDS area behind the waves' scratch.
+struct RlOpenWg {
+    uint32_t fin[RL_OPEN_CAP]; // per job: paths this workgroup finished (results acknowledged) and has not yet reported
+    uint32_t seg[RL_OPEN_CAP]; // per job: segments of paths this workgroup ended and has not yet reported
+    uint32_t flushed_at;       // wall clock (10 ns ticks, low 32 bits) of the last report to RlOpenDev
+    uint32_t poll[2];          // RlOpenDev::known as last read by a wave of this workgroup, and when
+    uint32_t pad;
 };
 
 // Scene::intersect (scene.rs:39-60) for the 64 rays of a wave.  Must be called by all 64 lanes in
@@ -461,12 +513,15 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // other's code and registers.
 // MULTI: the launch carries several render calls (job table); a compile-time switch so that a single call's launch
 // -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
-template <bool STAGE_LDS, bool FUSED, bool MULTI>
-__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
+// OPEN (implies MULTI): the job table is RlOpenDev::jobs and grows while the kernel runs (see above).
+template <bool STAGE_LDS, bool FUSED, bool MULTI, bool OPEN>
+// At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
+// the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
+__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                                   RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                                   float* __restrict__ plot,
                                                                   unsigned long long* __restrict__ queue,
-                                                                  const RlJobEntry* __restrict__ jobs) {
+                                                                  const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
     const RlF4* base = scene;
     RlWaveScratch* scratch = (RlWaveScratch*)smem;
@@ -518,9 +573,74 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
     p.ior = 1.0f;
     p.bounce = 0;
     uint32_t segments = 0, paths_done = 0;
+    // OPEN.  Finished paths are counted per job in the workgroup's LDS area and reported to the device-wide counters by
+    // one wave at a time, every ~30 us: every wave telling RlOpenDev itself (thousands of same-address atomics per job
+    // and more) measured 15-35 % of the kernel's time -- the returning atomics queue up and stall the waves.
+    // The results a count stands for must be visible to whatever kernel the host launches once the job is reported
+    // complete.  They are written as agent-scope atomics (write-through stores, memory-side float adds), and a path
+    // is counted one iteration after its result was issued, behind an s_waitcnt vmcnt(0) (all that a workgroup-scope
+    // release is on this target; a release at agent scope would write the whole L2 back, buffer_wbl2, every time).
+    uint32_t known_local = 0;          // wave-uniform: jobs known to this wave
+    uint64_t pend_mask = 0;            // wave-uniform: lanes whose path finished in the last iteration (my_job is still theirs)
+    uint32_t emit_pend = 0, emit_pend_base = 0; // wave-uniform: the emitter batch splatted in the last iteration
+    RlOpenWg* wgp = (RlOpenWg*)(scratch + RL_TRACE_BLOCK / 64);
+    RlLdsU32* wg_fin = (RlLdsU32*)&wgp->fin[0];
+    RlLdsU32* wg_seg = (RlLdsU32*)&wgp->seg[0];
+    RlLdsU32* wg_flushed_at = (RlLdsU32*)&wgp->flushed_at;
+    RlLdsU32* wg_poll = (RlLdsU32*)&wgp->poll[0];
     RlLdsF32* emit = (RlLdsF32*)&ws->emit[0][0];
+    if (OPEN) {
+        for (uint32_t i = threadIdx.x; i < sizeof(RlOpenWg) / 4; i += RL_TRACE_BLOCK) ((RlLdsU32*)wgp)[i] = 0;
+        __syncthreads();
+    }
+    // counts the paths whose results were issued an iteration ago
+    auto settle = [&]() {
+        if (pend_mask == 0 && emit_pend == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((pend_mask >> lane) & 1ull) __hip_atomic_fetch_add(wg_fin + my_job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane < emit_pend)
+            __hip_atomic_fetch_add(wg_fin + (rl_f2u(emit[4 * 128 + ((emit_pend_base + lane) & 127u)]) >> 24), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        pend_mask = 0;
+        emit_pend = 0;
+    };
+    // reports the workgroup's counts to RlOpenDev if nobody did in the last `gap` ticks; whoever completes a job tells the host
+    auto flush = [&](uint32_t gap) {
+        const uint32_t now = (uint32_t)wall_clock64();
+        uint32_t mine = gap == 0u ? 1u : 0u; // a wave that leaves reports whatever there is
+        if (lane == 0 && gap != 0u) {
+            uint32_t at = *wg_flushed_at;
+            if (now - at >= gap)
+                mine = __hip_atomic_compare_exchange_strong(wg_flushed_at, &at, now | 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_readfirstlane(mine) == 0u) return;
+        for (uint32_t base_job = 0; base_job < known_local; base_job += 64u) {
+            const uint32_t jb = base_job + lane;
+            uint32_t f = 0, sg = 0;
+            if (jb < known_local) { // fin before seg: every path counted in f has its segments in sg or in an earlier report
+                f = __hip_atomic_exchange(wg_fin + jb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                sg = __hip_atomic_exchange(wg_seg + jb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (__builtin_amdgcn_ballot_w64((f | sg) != 0u) == 0) continue;
+            if (sg != 0) __hip_atomic_fetch_add(&od->seg[jb], sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the segment counts are in before the path counts
+            if (f != 0) {
+                const uint32_t before = __hip_atomic_fetch_add(&od->fin[jb], f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + f == (uint32_t)od->jobs[jb].end) {
+                    __hip_atomic_fetch_add(&od->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t total = __hip_atomic_load(&od->seg[jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ctl->segs[jb], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef RL_OPEN_DEBUG
+                    ctl->t_done[jb] = wall_clock64();
+#endif
+                    __hip_atomic_store(&ctl->done[jb], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    };
     uint32_t e_head = 0, e_tail = 0; // wave-uniform ring indices of the emitter queue
-    bool ended_on_emitter = false;
+    bool ended_on_emitter = false, ended_now = false;
     uint32_t emit_obj = 0;
 #ifdef RL_STATS
     unsigned long long st[RL_ST_COUNT];
@@ -553,10 +673,18 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 }
             }
         }
+        if (OPEN) { // these paths are finished once the adds above are acknowledged: settle() counts them
+            emit_pend = count;
+            emit_pend_base = e_head;
+        }
         rl_wave_sync();
     };
 
     for (;;) {
+        if (OPEN) {
+            settle();
+            flush(3000u);
+        }
         // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
         RL_T0(t_refill);
         for (;;) {
@@ -566,7 +694,137 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             if (avail == 0) {
                 if (drained) break;
                 // Refill: all 64 lanes generate one camera ray each (full exec mask) into the stash.
-                if (chunk_next == chunk_end) {
+                uint32_t open_n = 0; // OPEN: size of the job the refill comes from
+                if (OPEN) {
+                    bool got = false;
+                    for (;;) {
+                        if (chunk_next < chunk_end) { // the rest of the slice this wave took last time
+                            open_n = (uint32_t)jobs[stash_job].end;
+                            got = true;
+                            break;
+                        }
+                        if (stash_job < known_local) { // take paths of the oldest job that has any left
+                            open_n = (uint32_t)jobs[stash_job].end;
+                            // One same-address atomic per 64 paths is about all the memory system does at the chip's path
+                            // rate (the waits queue up behind one another and stall the waves): with more calls waiting
+                            // behind this one a wave takes four refills at a time; a call on its own is spread thin so
+                            // that every wave gets some of it.
+                            const uint32_t take = known_local - stash_job >= 2u ? 256u : 64u;
+                            uint32_t b = 0;
+                            if (lane == 0) b = __hip_atomic_fetch_add(&od->next[stash_job], take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b = __builtin_amdgcn_readfirstlane(b);
+                            if (b < open_n) {
+                                chunk_end = b + take < open_n ? b + take : ((open_n + 63u) & ~63u);
+#ifdef RL_OPEN_DEBUG
+                                if (lane == 0 && b == 0) ctl->t_first[stash_job] = wall_clock64();
+                                if (lane == 0 && b + take >= open_n) ctl->t_last[stash_job] = wall_clock64();
+#endif
+                                chunk_next = b;
+                                got = true;
+                                break;
+                            }
+                            stash_job += 1u;
+                            continue;
+                        }
+                        // Out of known work.  Thousands of waves get here at about the same time and look again until
+                        // there is more: the device-wide words are read at most once per workgroup and 10 us (the
+                        // workgroup's last reading and its time are kept in LDS), or every such read queues up behind
+                        // the others' and the waves that are still tracing slow down several-fold.
+                        const uint32_t now = (uint32_t)wall_clock64();
+                        const uint32_t seen = __builtin_amdgcn_readfirstlane(wg_poll[0]), seen_at = __builtin_amdgcn_readfirstlane(wg_poll[1]);
+                        if (seen > known_local) {
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            known_local = seen;
+                            continue;
+                        }
+                        if (now - seen_at < 1000u) break;
+                        if (lane == 0) wg_poll[1] = now;
+                        uint32_t v = 0;
+                        if (lane == 0) v = __hip_atomic_load(&od->known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        v = __builtin_amdgcn_readfirstlane(v);
+                        if (v > known_local) {
+                            if (lane == 0) wg_poll[0] = v;
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                            known_local = v;
+                            continue;
+                        }
+                        if (lane == 0) v = __hip_atomic_load(&od->closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_readfirstlane(v) != 0u) {
+                            drained = true;
+                            break;
+                        }
+                        // Every known job is handed out: one wave at a time asks the host for more, or closes the launch.
+                        if (lane == 0) {
+                            uint32_t expected = 0;
+                            v = __hip_atomic_compare_exchange_strong(&od->closing, &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+                        }
+                        if (__builtin_amdgcn_readfirstlane(v) == 0u) break; // somebody else is at it: look again next iteration
+                        uint32_t pub = 0;
+                        if (lane == 0) pub = __hip_atomic_load(&ctl->published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        pub = __builtin_amdgcn_readfirstlane(pub);
+                        if (pub > RL_OPEN_CAP) pub = RL_OPEN_CAP;
+                        if (pub > known_local) { // new calls: copy their entries to device memory, then make them known
+                            for (uint32_t k = known_local + lane; k < pub; k += 64u) {
+#ifdef RL_OPEN_DEBUG
+                                ctl->t_known[k] = wall_clock64();
+#endif
+                                unsigned long long* dst = (unsigned long long*)&od->jobs[k];
+                                const unsigned long long* src = (const unsigned long long*)&ctl->jobs[k];
+                                for (int w = 0; w < 4; ++w)
+                                    __hip_atomic_store(dst + w, __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                            if (lane == 0) {
+                                od->idle_since = 0;
+                                od->stuck_since = 0;
+                                wg_poll[0] = pub;
+                                __hip_atomic_store(&od->known, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&od->closing, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            known_local = pub;
+                            continue;
+                        }
+                        // Nothing new.  While calls of this launch are still finishing their last paths the kernel is
+                        // running anyway, and their callers come back with the next batch the moment they are told: stay
+                        // open until every call is complete and then for a grace period (job.reserved ticks of 10 ns).
+                        uint32_t stay = 0;
+                        if (lane == 0 && known_local < RL_OPEN_CAP) {
+                            const bool finishing = __hip_atomic_load(&od->completed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < known_local;
+                            const unsigned long long now = wall_clock64(), since = finishing ? od->stuck_since : od->idle_since;
+                            // (a call that never completes would be a bug in the counting above: after 5 s without one
+                            // the launch ends regardless, and the host reports the call that is missing)
+                            const unsigned long long limit = finishing ? 500000000ull : (unsigned long long)job.reserved;
+                            if (since == 0) (finishing ? od->stuck_since : od->idle_since) = now, stay = 1;
+                            else if (now - since < limit) stay = 1;
+                            if (!finishing) od->stuck_since = 0;
+                            if (stay) __hip_atomic_store(&od->closing, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (__builtin_amdgcn_readfirstlane(stay) != 0u) break;
+                        uint32_t again = 0;
+                        if (lane == 0) {
+                            __hip_atomic_store(&ctl->closed_at, known_local, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+                            again = __hip_atomic_load(&ctl->published, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        again = __builtin_amdgcn_readfirstlane(again);
+                        if (again == known_local || known_local >= RL_OPEN_CAP) { // nothing arrived: the launch is closed for good
+                            if (lane == 0) {
+                                __hip_atomic_store(&ctl->final_at, known_local, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                                __hip_atomic_store(&od->closed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            drained = true;
+                            break;
+                        }
+                        if (lane == 0) { // a call arrived in between: re-open and pick it up in the next round
+                            __hip_atomic_store(&ctl->closed_at, RL_OPEN_NONE, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(&od->closing, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    if (!got) break; // no paths to hand out right now (or ever again, if drained)
+                }
+                if (!OPEN && chunk_next == chunk_end) {
                     // Small launches (fewer than 16 paths per lane of the grid: the reference's 524,288-path
                     // batch is 2 per lane) take one stash refill at a time, so that every wave gets work;
                     // with RL_CHUNK the first half of the waves would take everything.
@@ -580,13 +838,14 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     chunk_end = chunk_next + chunk;
                 }
                 RL_STAT(RL_ST_REFILLS, 1);
-                if (MULTI) { // all 64 offsets of a refill lie in one call; a wave's offsets only grow
+                if (MULTI && !OPEN) { // all 64 offsets of a refill lie in one call; a wave's offsets only grow
                     while (stash_job + 1u < job.n_jobs && chunk_next >= jobs[stash_job].end) stash_job += 1u;
                     stash_first = jobs[stash_job].first_path - jobs[stash_job].start;
                 }
+                if (OPEN) stash_first = jobs[stash_job].first_path;
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
-                const bool valid = offset < job.n_paths;
+                const bool valid = offset < (OPEN ? (uint64_t)open_n : job.n_paths);
                 const uint64_t path_index = stash_first + offset;
                 RlPath fresh = p;
                 RL_T0(t_cam);
@@ -608,7 +867,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                 rl_wave_sync();
                 stash_head = 0;
                 stash_count = 64;
-                if (chunk_next >= job.n_paths) drained = true;
+                if (!OPEN && chunk_next >= job.n_paths) drained = true;
                 continue;
             }
             const uint32_t rank = rl_mbcnt(need);
@@ -634,7 +893,20 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
             stash_head += wanted < avail ? wanted : avail;
         }
         RL_T1(RL_ST_T_REFILL, t_refill);
-        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) {
+            if (!OPEN || drained) break;
+            // an open launch with nothing to hand out at the moment: report what is finished (the host may be waiting
+            // for exactly that before it sends more) and look again
+            settle();
+            if (FUSED && e_tail != e_head) {
+                process_emitted(e_tail - e_head);
+                e_head = e_tail;
+                settle();
+            }
+            flush(500u);
+            for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
+            continue;
+        }
         const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
@@ -679,7 +951,14 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     ph.y = p.sy;
                     ph.probability = value;
                     ph.wavelength = p.wavelength;
-                    if (MULTI) {
+                    if (OPEN) { // write-through (see `report`): the reader is a kernel launched while this one still runs
+                        const RlJobEntry e = jobs[my_job];
+                        uint32_t* dst = (uint32_t*)&((RlMappedPhoton*)e.target)[my_path - e.first_path];
+                        __hip_atomic_store(dst + 0, rl_f2u(ph.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 1, rl_f2u(ph.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 2, rl_f2u(ph.probability), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(dst + 3, rl_f2u(ph.wavelength), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (MULTI) {
                         const RlJobEntry e = jobs[my_job];
                         ((RlMappedPhoton*)e.target)[my_path - e.first_path] = ph;
                     } else {
@@ -689,7 +968,17 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
                     ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
                     emit_obj = MULTI ? (emitter | (my_job << 24)) : emitter; // merged launches: the call, i.e. the plot buffer
                 }
+                if (OPEN) { // trace_unit.rs:92-131: the Void and a light end the path in the scan's iteration, roulette after the bounce
+                    ended_now = true;
+                    __hip_atomic_fetch_add(wg_seg + my_job, p.bounce + ((hit.obj == RL_HIT_NONE || status == RL_PATH_ENDED_ON_EMITTER) ? 1u : 0u),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
+        }
+        if (OPEN) {
+            // a path that ended on a light is finished when it is splatted (process_emitted), every other one now
+            pend_mask = __builtin_amdgcn_ballot_w64(ended_now && !(FUSED && ended_on_emitter));
+            ended_now = false;
         }
         RL_T1(RL_ST_T_SHADE, t_shade);
         RL_T0(t_emit);
@@ -716,6 +1005,10 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) void rl_trace_kernel(const RlF4*
         RL_T1(RL_ST_T_EMIT, t_emit);
     }
     if (FUSED && e_tail != e_head) process_emitted(e_tail - e_head);
+    if (OPEN) {
+        settle();
+        flush(0u);
+    }
     RL_T1(RL_ST_T_TOTAL, t_total);
 #ifdef RL_STATS
     if (lane == 0)
