@@ -152,11 +152,13 @@ int rl_trace_unit_destroy(RlTraceUnit* unit);
 int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
 /* TraceUnit::render(&mut self, &Scene) (trace_unit.rs:151-168): fills the unit's mapped_photons.
  * Photon i of this call is path (first_path_index + i) of RNG stream `stream` under `seed`.
- * Complete (device-synchronised) on return.  Calls made at the same time from several threads (the reference's
- * workers, app.rs:92-134) on units of one device with the same scene, seed, stream, image and batch size are
- * merged into ONE kernel launch behind this call -- the results are bit-identical to separate launches; the
- * device-time and path counters of a merged launch are accounted to the unit whose thread issued it
- * (rl_trace_unit_stats sums over the units of a run stay exact). */
+ * Complete on return: mapped_photons may be plotted or downloaded.  Calls made from several threads (the reference's
+ * workers, app.rs:92-134) on units of one device with the same scene, seed, stream and image size share OPEN
+ * LAUNCHES: a call whose batch is a multiple of 64 paths is appended to a trace kernel that is already running on
+ * the device if there is one (otherwise it starts one), and returns as soon as ITS paths are finished while the
+ * kernel goes on with the other callers' -- so nothing is launched per call and the drain tail of one batch overlaps
+ * the next batches.  The results are bit-identical to separate launches.  Path and segment counters are kept per
+ * call; the kernel time of an open launch is credited to the first of its units asked for rl_trace_unit_stats. */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
 /* The same without the final wait: the launch is queued on the unit's stream and rl_trace_unit_sync() (or
@@ -171,10 +173,10 @@ int rl_trace_unit_render_async(RlTraceUnit* unit, const RlScene* scene, uint64_t
  * rl_trace_unit_sync() or any download waits for it. */
 int rl_trace_unit_render_fused(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
-/* The same, complete on return, for hosts whose workers wait for their task anyway (the reference's do): calls in
- * flight together on units of one device (same scene, seed, stream, image size; n_paths a multiple of 64) are merged
- * into ONE launch that splats into every call's plot unit -- the batches of several Plot tasks share one drain tail.
- * Results are those of separate calls up to the order of the float atomics. */
+/* The same, complete on return, for hosts whose workers wait for their task anyway (the reference's do): calls on
+ * units of one device (same scene, seed, stream, image size; n_paths a multiple of 64) share open launches like
+ * rl_trace_unit_render's, each splatting into its own call's plot unit.  Results are those of separate calls up to
+ * the order of the float atomics. */
 int rl_trace_unit_render_fused_sync(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                     uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
 int rl_trace_unit_sync(RlTraceUnit* unit);
@@ -334,9 +336,9 @@ typedef struct RlAppConfig {
                                     unit is one unit per rank, rank r uses RNG stream `stream + r`, and Task::Gather
                                     sums the ranks' plot buffers onto rank 0 first (rl_plot_unit_reduce over xGMI for
                                     distinct GPUs, rl_plot_unit_add for ranks that share one) */
-    int queued_trace;            /* 0 (default): a worker waits for the launch its task issued -- un-fused, a Trace task is the
-                                    blocking rl_trace_unit_render, like a reference worker, and concurrent workers' calls are
-                                    merged into one launch (see there); fused, a Plot task waits for its launch.  Non-zero: the
+    int queued_trace;            /* 0 (default): a worker waits for the paths its task asked for -- un-fused, a Trace task is the
+                                    blocking rl_trace_unit_render, like a reference worker, and the workers' calls share open
+                                    launches (see there); fused, a Plot task does the same with rl_trace_unit_render_fused_sync.  Non-zero: a
                                     launch is queued and the worker moves on (the device orders Plot after Trace and Gather
                                     after Plot by itself; a unit's previous launch is waited for before it is used again).
                                     Measured slower un-fused, equal fused, at the reference's task size */

@@ -126,7 +126,7 @@ class TraceUnit(_Handle):
                                              n_paths))
 
     def render_fused_sync(self, scene, plot_unit, n_paths, seed=1, stream=0, first_path_index=0):
-        """Blocking fused render; concurrent calls (several threads) are merged into one launch."""
+        """Blocking fused render; the calls of several threads share open launches (rl_trace_unit_render_fused_sync)."""
         check(lib.rl_trace_unit_render_fused_sync(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index, n_paths))
 
     def sync(self):
@@ -362,7 +362,7 @@ def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_bat
 
 
 def batch_histogram(device=0):
-    """{k: launches that carried k merged TraceUnit.render calls} since the library was loaded."""
+    """{k: open launches that carried k blocking render calls} since the library was loaded (waits for running ones)."""
     out = (C.c_uint64 * 257)()
     check(lib.rl_debug_batch_histogram(device, out))
     return {k: int(out[k]) for k in range(1, 257) if out[k]}

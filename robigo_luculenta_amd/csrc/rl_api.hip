@@ -85,17 +85,14 @@ struct RlTraceUnit {
     RlMappedPhoton* photons;
     unsigned long long* queue; // 3 counters, see rl_trace_kernel
     hipStream_t stream;
-    hipEvent_t rendered; // recorded after every launch that fills this unit's photons (on the launching unit's stream)
-    hipEvent_t guard;    // merged launches: carries "everything queued on `stream` so far" (a pending plot) to the leader
+    hipEvent_t rendered; // recorded on `stream` after everything that fills this unit's photons
     int fetch;
     int cu_count;
     std::vector<EventPair> pending, pool;
     double kernel_ms;
     uint64_t launches;
-    RlJobEntry* job_table;            // device copy of a merged launch's job list (RL_MAX_MERGED_JOBS entries)
-    std::vector<RlJobEntry> job_host; // its host source: must outlive the asynchronous copy
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
-    bool tuned_stage, tuned_fused, tuned_multi; // kernel variant,
+    bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
     uint64_t session_paths = 0, session_segments = 0; // of this unit's calls that open launches served
 };
@@ -149,28 +146,10 @@ int drain_events(RlTraceUnit* u) {
     return RL_OK;
 }
 
-#define RL_MAX_MERGED_JOBS 64
-#define RL_MAX_LAUNCHES_IN_FLIGHT 2
-
-// One render call inside a merged launch: un-fused (plot == nullptr) it fills unit->mapped_photons with n_paths =
-// unit->n_photons paths, fused it splats n_paths paths into plot's buffer.
-struct MergedJob {
-    RlTraceUnit* unit;
-    RlPlotUnit* plot;
-    uint64_t first_path, n_paths;
-};
-
-// One launch of the trace kernel on u's stream.  `merged` (may be null) lists the calls this launch carries (all
-// fused or all un-fused, every n_paths a multiple of 64): consecutive offset ranges of the launch, one per call.
+// One launch of the trace kernel on u's stream: n_paths paths from first_path on, into `photons` (un-fused) or splatted
+// into plot_unit's buffer (fused).
 int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
-                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths, const MergedJob* merged = nullptr,
-                 uint32_t n_merged = 0, uint32_t max_blocks = 0) {
-    if (n_merged > 1) {
-        n_paths = 0;
-        for (uint32_t k = 0; k < n_merged; ++k) n_paths += merged[k].n_paths;
-        first_path = 0;
-        plot_unit = merged[0].plot; // only selects the fused kernel; the targets come from the job table
-    }
+                 uint32_t stream_id, uint64_t first_path, uint64_t n_paths) {
     if (n_paths == 0) return RL_OK;
     if (first_path + n_paths < first_path || first_path + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
@@ -184,33 +163,18 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.seed = seed;
     job.first_path = first_path;
     job.n_paths = n_paths;
-    job.n_jobs = 1;
+    job.grace_ticks = 0;
     job.reserved = 0;
-    if (n_merged > 1) {
-        job.n_jobs = n_merged;
-        u->job_host.resize(n_merged);
-        uint64_t start = 0;
-        for (uint32_t k = 0; k < n_merged; ++k) {
-            u->job_host[k].target = merged[k].plot ? (void*)merged[k].plot->xyz : (void*)merged[k].unit->photons;
-            u->job_host[k].first_path = merged[k].first_path;
-            u->job_host[k].start = start;
-            start += merged[k].n_paths;
-            u->job_host[k].end = start;
-        }
-    }
 
     // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
     const size_t blob_bytes = scene->staged_bytes;
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     const bool fused = plot != nullptr;
-    const bool multi = n_merged > 1;
-    auto kernel = multi ? (stage ? (fused ? rl_trace_kernel<true, true, true, false> : rl_trace_kernel<true, false, true, false>)
-                                 : (fused ? rl_trace_kernel<false, true, true, false> : rl_trace_kernel<false, false, true, false>))
-                        : (stage ? (fused ? rl_trace_kernel<true, true, false, false> : rl_trace_kernel<true, false, false, false>)
-                                 : (fused ? rl_trace_kernel<false, true, false, false> : rl_trace_kernel<false, false, false, false>));
+    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, false> : rl_trace_kernel<true, false, false>)
+                        : (fused ? rl_trace_kernel<false, true, false> : rl_trace_kernel<false, false, false>);
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
-    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused || u->tuned_multi != multi) { // once per (unit, scene size, variant)
+    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int per_cu = 1;
@@ -219,14 +183,10 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         u->tuned_dyn = dyn;
         u->tuned_stage = stage;
         u->tuned_fused = fused;
-        u->tuned_multi = multi;
     }
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
-    if (max_blocks != 0 && blocks > max_blocks) blocks = max_blocks; // this launch's share of the CUs (the batcher)
-    static const uint64_t env_blocks = getenv("RL_TRACE_MAX_BLOCKS") ? (uint64_t)atoll(getenv("RL_TRACE_MAX_BLOCKS")) : 0; // experiments
-    if (env_blocks != 0 && blocks > env_blocks) blocks = env_blocks;
 
     EventPair ep;
     if (!u->pool.empty()) {
@@ -236,29 +196,15 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         RL_HIP(hipEventCreate(&ep.start));
         RL_HIP(hipEventCreate(&ep.stop));
     }
-    if (n_merged <= 1 && plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
+    if (plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
-    if (n_merged > 1) {
-        RL_HIP(hipMemcpyAsync(u->job_table, u->job_host.data(), n_merged * sizeof(RlJobEntry), hipMemcpyHostToDevice, u->stream));
-        for (uint32_t k = 0; k < n_merged; ++k) {
-            if (merged[k].plot) RL_HIP(hipStreamWaitEvent(u->stream, merged[k].plot->cleared, 0));
-            if (merged[k].unit != u) { // whatever is queued on that unit's stream (a pending plot reading its photons) first
-                RL_HIP(hipEventRecord(merged[k].unit->guard, merged[k].unit->stream));
-                RL_HIP(hipStreamWaitEvent(u->stream, merged[k].unit->guard, 0));
-            }
-        }
-    }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
-                       plot, u->queue, (const RlJobEntry*)u->job_table, (RlOpenDev*)nullptr, (RlOpenCtl*)nullptr);
+                       plot, u->queue, (const RlJobEntry*)nullptr, (RlOpenDev*)nullptr, (RlOpenCtl*)nullptr);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
     RL_HIP(hipEventRecord(u->rendered, u->stream));
-    for (uint32_t k = 0; k < n_merged; ++k) {
-        if (merged[k].unit != u) RL_HIP(hipEventRecord(merged[k].unit->rendered, u->stream));
-        if (n_merged > 1 && merged[k].plot) RL_HIP(hipStreamWaitEvent(merged[k].plot->stream, u->rendered, 0));
-    }
-    if (n_merged <= 1 && plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
+    if (plot_unit) RL_HIP(hipStreamWaitEvent(plot_unit->stream, u->rendered, 0)); // the plot stream's tail covers this splat
     u->pending.push_back(ep);
     u->launches += 1;
     if (u->pending.size() > 512) return drain_events(u);
@@ -458,15 +404,13 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->photons = nullptr;
     u->queue = nullptr;
     u->stream = nullptr;
-    u->rendered = u->guard = nullptr;
-    u->job_table = nullptr;
+    u->rendered = nullptr;
     u->fetch = RL_FETCH_LDS;
     u->kernel_ms = 0.0;
     u->launches = 0;
     u->tuned_dyn = 0;
     u->tuned_stage = false;
     u->tuned_fused = false;
-    u->tuned_multi = false;
     u->tuned_per_cu = 0;
     u->cu_count = 256;
     hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));
@@ -475,8 +419,6 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     if (e == hipSuccess) e = hipMemset(u->queue, 0, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->rendered, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->guard, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void**)&u->job_table, RL_MAX_MERGED_JOBS * sizeof(RlJobEntry));
     if (e == hipSuccess) e = hipDeviceSynchronize(); // the memsets above ran on the null stream
     if (e != hipSuccess) {
         rl_trace_unit_destroy(u);
@@ -504,8 +446,6 @@ int rl_trace_unit_destroy(RlTraceUnit* u) {
     }
     if (u->stream) (void)hipStreamDestroy(u->stream);
     if (u->rendered) (void)hipEventDestroy(u->rendered);
-    if (u->guard) (void)hipEventDestroy(u->guard);
-    if (u->job_table) (void)hipFree(u->job_table);
     if (u->photons) (void)hipFree(u->photons);
     if (u->queue) (void)hipFree(u->queue);
     delete u;
@@ -525,58 +465,6 @@ int rl_trace_unit_render_async(RlTraceUnit* u, const RlScene* scene, uint64_t se
     if (rc != RL_OK) return rc;
     return launch_trace(u, scene, u->photons, nullptr, seed, stream, first_path_index, u->n_photons);
 }
-
-// TraceUnit::render as the reference's workers call it: blocking, one 524,288-path batch per call (trace_unit.rs:67).
-// That batch is 0.15 ms of MI355X work followed by ~0.2 ms in which the launch waits for its longest paths, so one
-// launch per call leaves half the chip idle.  Calls that are in flight at the same time -- the reference runs one
-// per worker thread -- are therefore MERGED: whichever caller finds a launch slot free takes every compatible call
-// queued at that moment (same scene, seed, stream, image size, batch size, fetch mode) and issues them as one
-// launch whose job table names each unit's photons and path range (RlJobEntry); the callers return when that
-// launch is complete.  Results are those of separate launches, bit for bit: a path is a pure function of
-// (seed, stream, path index).  A lone caller is launched at once -- nothing ever waits for company.
-//
-// Up to RL_MAX_LAUNCHES_IN_FLIGHT launches run per device (the HIP runtime drives 4 hardware queues), and each
-// takes only its SHARE of the CUs: (calls it carries) / (calls currently inside this function), a little
-// over-subscribed.  A launch is persistent waves, so its drain tail idles whatever CUs it holds; with every call
-// spread over the whole chip the tails of successive launches add up (46 % of the bulk rate at the reference's task
-// size), with the chip divided among concurrent launches a tail idles only that launch's share while the others
-// keep computing, and the over-subscription lets a queued launch start on CUs as they drain.
-namespace {
-
-struct RenderCall {
-    RlTraceUnit* unit;
-    RlPlotUnit* plot; // fused call: the target; un-fused: nullptr
-    const RlScene* scene;
-    uint64_t seed, first_path, n_paths;
-    uint32_t stream;
-    int rc = RL_OK;
-    std::string error;
-    bool taken = false, done = false;
-};
-
-struct DeviceBatcher {
-    std::mutex lock;
-    std::condition_variable changed;
-    std::vector<RenderCall*> waiting;
-    int in_flight = 0;
-    int callers = 0;      // threads inside rl_trace_unit_render
-    int peak_callers = 0; // the most seen at once (how many workers the host runs)
-    uint64_t histogram[RL_MAX_MERGED_JOBS + 1] = {}; // launches by number of merged calls (rl_debug_batch_histogram)
-};
-
-DeviceBatcher* batcher_of(int device) {
-    static DeviceBatcher batchers[64];
-    return &batchers[device >= 0 && device < 64 ? device : 0];
-}
-
-bool mergeable(const RenderCall& a, const RenderCall& b) {
-    const RlTraceUnit *x = a.unit, *y = b.unit;
-    return a.scene == b.scene && a.seed == b.seed && a.stream == b.stream && x->width == y->width && x->height == y->height &&
-           x->fetch == y->fetch && x->device == y->device && x != y && (a.plot != nullptr) == (b.plot != nullptr) &&
-           (a.plot == nullptr || a.plot != b.plot) && b.n_paths % 64 == 0 && b.n_paths != 0;
-}
-
-} // namespace
 
 namespace {
 
@@ -615,18 +503,13 @@ struct DeviceSessions {
     uint64_t launches = 0;
     double kernel_ms = 0.0; // of finished kernels, not yet credited to a trace unit (rl_trace_unit_stats)
     uint64_t histogram[RL_OPEN_CAP + 1] = {}; // finished kernels by number of calls they carried
-    double presync_us = 0.0, admit_us = 0.0, wait_us = 0.0; // where the calls spent their time (RL_SESSION_TIMING=1 prints it)
+    double presync_us = 0.0, admit_us = 0.0, wait_us = 0.0; // where the calls spent their time (RL_OPEN_LAUNCH_TIMING=1 prints it)
     uint64_t calls = 0, starts = 0;
 };
 
 DeviceSessions* sessions_of(int device) {
     static DeviceSessions all[64];
     return &all[device >= 0 && device < 64 ? device : 0];
-}
-
-bool sessions_enabled() {
-    static const bool on = !(getenv("RL_SESSIONS") && atoi(getenv("RL_SESSIONS")) == 0);
-    return on;
 }
 
 inline uint32_t host_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
@@ -638,15 +521,7 @@ int sessions_setup(DeviceSessions* d) { // under d->lock, device current
     for (Session& x : d->s) {
         // a priority of its own = a hardware queue of its own: the streams of the plot / gather / tonemap kernels must
         // never queue up behind a resident trace kernel (they run beside it in the registers it leaves free)
-        const char* how = getenv("RL_SESSION_STREAM"); // experiment
-        if (how && !strcmp(how, "high")) RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, greatest));
-        else if (how && !strcmp(how, "normal")) RL_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
-        else if (how && !strcmp(how, "cumask")) {
-            uint32_t mask[8];
-            for (int i = 0; i < 8; ++i) mask[i] = 0xffffffffu;
-            RL_HIP(hipExtStreamCreateWithCUMask(&x.stream, 8, mask));
-        } else RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, least));
-        if (getenv("RL_SESSION_TIMING")) fprintf(stderr, "stream priority range: least %d greatest %d\n", least, greatest);
+        RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, least));
         RL_HIP(hipMalloc((void**)&x.od, sizeof(RlOpenDev)));
         RL_HIP(hipHostMalloc((void**)&x.ctl, sizeof(RlOpenCtl), hipHostMallocCoherent | hipHostMallocMapped));
         RL_HIP(hipHostGetDevicePointer((void**)&x.ctl_dev, x.ctl, 0));
@@ -705,13 +580,13 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     job.seed = seed;
     job.first_path = 0;
     job.n_paths = 0;
-    job.n_jobs = 0;
-    static const uint32_t grace_us = getenv("RL_SESSION_GRACE_US") ? (uint32_t)atoi(getenv("RL_SESSION_GRACE_US")) : 150u;
-    job.reserved = grace_us * 100u; // ticks of wall_clock64() (100 MHz) an idle open launch waits for another call
+    static const uint32_t grace_us = getenv("RL_OPEN_LAUNCH_GRACE_US") ? (uint32_t)atoi(getenv("RL_OPEN_LAUNCH_GRACE_US")) : 150u;
+    job.grace_ticks = grace_us * 100u; // ticks of wall_clock64() (100 MHz) an idle open launch waits for another call
+    job.reserved = 0;
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
     const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
-    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true, true> : rl_trace_kernel<true, false, true, true>)
-                        : (fused ? rl_trace_kernel<false, true, true, true> : rl_trace_kernel<false, false, true, true>);
+    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)
+                        : (fused ? rl_trace_kernel<false, true, true> : rl_trace_kernel<false, false, true>);
     const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
     RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     int per_cu = 1;
@@ -858,87 +733,29 @@ int render_session(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint6
 
 #define RL_SESSION_MAX_PATHS (1ull << 28) // per call: its segment count must fit 32 bits
 
-// The blocking render of both kinds behind the batcher: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
+// The blocking render of both kinds: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
 int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream, uint64_t first_path_index,
                     uint64_t n_paths) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
     if (n_paths == 0) return RL_OK;
-    if (sessions_enabled() && n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS)
-        return render_session(u, scene, plot, seed, stream, first_path_index, n_paths);
-    DeviceBatcher* b = batcher_of(u->device);
-    RenderCall me;
-    me.unit = u;
-    me.plot = plot;
-    me.scene = scene;
-    me.seed = seed;
-    me.first_path = first_path_index;
-    me.n_paths = n_paths;
-    me.stream = stream;
-    std::unique_lock<std::mutex> guard(b->lock);
-    b->waiting.push_back(&me);
-    b->callers += 1;
-    if (b->callers > b->peak_callers) b->peak_callers = b->callers;
-    int lingered = 0;
-    for (;;) {
-        if (me.done) break;
-        if (me.taken || b->in_flight >= RL_MAX_LAUNCHES_IN_FLIGHT) { // somebody leads my call, or every launch slot is busy
-            b->changed.wait(guard);
-            continue;
-        }
-        // A launch is already running, so there is no hurry: give the other workers a moment to arrive and share the
-        // launch (and its drain tail) -- until half of them are here, or the GPU runs dry, or ~150 us have passed.
-        if (b->in_flight >= 1 && lingered < 3 && (int)b->waiting.size() * 2 < b->peak_callers) {
-            lingered += 1;
-            b->changed.wait_for(guard, std::chrono::microseconds(50));
-            continue;
-        }
-        // Lead: my call plus every compatible one waiting right now (merging needs batch sizes the kernel can map
-        // back to a job per stash refill: multiples of RL_CHUNK).
-        std::vector<RenderCall*> group;
-        const bool can_merge = n_paths % 64 == 0;
-        for (RenderCall* c : b->waiting)
-            if (!c->taken && (c == &me || (can_merge && group.size() < RL_MAX_MERGED_JOBS && mergeable(me, *c)))) {
-                c->taken = true;
-                group.push_back(c);
-            }
-        std::vector<RenderCall*> rest;
-        for (RenderCall* c : b->waiting)
-            if (!c->taken) rest.push_back(c);
-        b->waiting.swap(rest);
-        b->in_flight += 1;
-        b->histogram[group.size()] += 1;
-        const uint32_t max_blocks = 0; // the whole chip: dividing the CUs among concurrent launches measured slower
-        guard.unlock();
-        int launch_rc;
-        if (group.size() == 1) {
-            launch_rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths, nullptr, 0,
-                                     max_blocks);
-        } else {
-            std::vector<MergedJob> jobs;
-            for (RenderCall* c : group) jobs.push_back(MergedJob{c->unit, c->plot, c->first_path, c->n_paths});
-            launch_rc = launch_trace(u, scene, nullptr, nullptr, seed, stream, 0, 0, jobs.data(), (uint32_t)jobs.size(), max_blocks);
-        }
-        if (launch_rc == RL_OK && hipStreamSynchronize(u->stream) != hipSuccess) launch_rc = fail(RL_E_HIP, "hipStreamSynchronize failed");
-        const std::string message = launch_rc == RL_OK ? std::string() : g_error;
-        guard.lock();
-        b->in_flight -= 1;
-        for (RenderCall* c : group) {
-            c->rc = launch_rc;
-            c->error = message;
-            c->done = true;
-        }
-        b->changed.notify_all();
-    }
-    b->callers -= 1;
-    if (b->callers == 0 && b->peak_callers > 1) b->peak_callers -= 1; // forget a host that has fewer workers now
-    guard.unlock();
-    if (me.rc != RL_OK) return fail(me.rc, me.error);
+    if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
+    if (first_path_index + n_paths < first_path_index || first_path_index + n_paths == ~0ull)
+        return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
+    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return render_session(u, scene, plot, seed, stream, first_path_index, n_paths);
+    // a ragged or a huge batch: a launch of its own
+    rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
 
 } // namespace
 
+// TraceUnit::render as the reference's workers call it: blocking, one 524,288-path batch per call (trace_unit.rs:67).
+// That batch is 0.15 ms of MI355X work followed by ~0.2 ms in which the launch waits for its longest paths, so the
+// calls that are in flight at the same time -- the reference runs one per worker thread -- share OPEN launches (above).
+// Results are those of separate launches, bit for bit: a path is a pure function of (seed, stream, path index).
 int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
     if (!u || !scene) return fail(RL_E_INVALID, "null handle");
     return render_blocking(u, scene, nullptr, seed, stream, first_path_index, u->n_photons);
@@ -1522,18 +1339,13 @@ int rl_gather_unit_allreduce(RlGatherUnit* gather, RlPlotUnit* plot, RlComm* com
 int rl_debug_batch_histogram(int device, uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
     for (uint32_t k = 0; k <= RL_OPEN_CAP; ++k) out[k] = 0;
-    {
-        DeviceBatcher* b = batcher_of(device);
-        std::lock_guard<std::mutex> guard(b->lock);
-        for (int k = 0; k <= RL_MAX_MERGED_JOBS; ++k) out[k] = b->histogram[k];
-    }
     int rc = use_device(device);
     if (rc == RL_OK) rc = sessions_quiesce(device, nullptr); // the open launches still running end first: then they are counted
     if (rc != RL_OK) return rc;
     DeviceSessions* d = sessions_of(device);
     std::lock_guard<std::mutex> guard(d->lock);
     for (uint32_t k = 0; k <= RL_OPEN_CAP; ++k) out[k] += d->histogram[k];
-    if (getenv("RL_SESSION_TIMING") && d->calls)
+    if (getenv("RL_OPEN_LAUNCH_TIMING") && d->calls)
         fprintf(stderr, "open launches on device %d: %llu calls, mean us per call: wait for the target %.1f, admission %.1f, completion %.1f\n",
                 device, (unsigned long long)d->calls, d->presync_us / d->calls, d->admit_us / d->calls, d->wait_us / d->calls);
     d->presync_us = d->admit_us = d->wait_us = 0.0;

@@ -190,14 +190,14 @@ void execute_task(AppState& a, const RlTask& task) {
         break;
     case RL_TASK_TRACE: // app.rs:132-134, on every rank at once
         if (!c.fused) {
-            // Default: the blocking rl_trace_unit_render, like a reference worker -- the library merges the calls of
-            // concurrent workers into one launch per device (measured: 7.3 Grays/s at 8 workers against 6.1 for
-            // queueing every batch as its own launch and moving on, RlAppConfig::queued_trace).
-            // With several ranks the launches are started on every device before any is waited for (un-merged).
-            const bool merged_blocking = !c.queued_trace && a.ranks.size() == 1;
+            // Default: the blocking rl_trace_unit_render, like a reference worker -- the workers' calls share open
+            // launches on the device (measured: 11.3 Grays/s at 8 workers against 6.8 for queueing every batch as its
+            // own launch and moving on, RlAppConfig::queued_trace).
+            // With several ranks one launch per batch is started on every device before any is waited for.
+            const bool shared_blocking = !c.queued_trace && a.ranks.size() == 1;
             for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
                 RlTraceUnit* u = a.ranks[r].trace_units[task.unit];
-                if (merged_blocking) {
+                if (shared_blocking) {
                     rc = rl_trace_unit_render(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 } else {
                     rc = rl_trace_unit_sync(u); // back-pressure: this unit's previous launch (long finished, normally)
@@ -205,7 +205,7 @@ void execute_task(AppState& a, const RlTask& task) {
                         rc = rl_trace_unit_render_async(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 }
             }
-            if (!merged_blocking && !c.queued_trace)
+            if (!shared_blocking && !c.queued_trace)
                 for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
         }
         // fused: the photons are produced when the unit is plotted (the target buffer is known then)
@@ -227,7 +227,7 @@ void execute_task(AppState& a, const RlTask& task) {
                 const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
                 const uint64_t first = a.fused_next_path.fetch_add(n);
                 if (!c.queued_trace && a.ranks.size() == 1) {
-                    // the blocking call: Plot tasks of concurrent workers share one launch (and one drain tail)
+                    // the blocking call: the workers' Plot tasks share open launches on the device
                     rc = rl_trace_unit_render_fused_sync(a.ranks[0].trace_units[task.units[0]], a.ranks[0].scene, a.ranks[0].plot_units[task.unit],
                                                          c.seed, c.stream, first, n);
                 } else {

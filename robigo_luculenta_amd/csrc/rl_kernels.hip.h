@@ -41,19 +41,19 @@ struct RlTraceJob {
     float aspect_ratio;
     uint32_t stream;
     uint64_t seed;
-    uint64_t first_path;     // single job: path index of offset 0
-    uint64_t n_paths;        // all jobs together
-    uint32_t n_jobs;         // > 1: a merged launch of several render calls (rl_api.hip's batcher)
+    uint64_t first_path;     // plain launch: path index of offset 0
+    uint64_t n_paths;        // plain launch: number of paths
+    uint32_t grace_ticks;    // open launch: how long (10 ns ticks) it waits for another call once every call is complete
     uint32_t reserved;
 };
 
-// One call of a merged launch: offsets [start, end) of the launch are the path indices first_path .. of this call
-// and go to `target` (un-fused: the unit's mapped_photons; fused: the plot unit's tristimulus buffer).  start and
-// end are multiples of 64, so the 64 offsets of a stash refill always belong to one call.
+// One call of an open launch: its path offsets [0, end) are the path indices first_path .. of the call's RNG stream and
+// go to `target` (un-fused: the unit's mapped_photons; fused: the plot unit's tristimulus buffer).  end is a multiple
+// of 64, so the 64 paths of a stash refill always belong to one call.
 struct RlJobEntry {
     void* target;
     uint64_t first_path;
-    uint64_t start, end;
+    uint64_t start, end; // start = 0
 };
 
 // ---- open launches ("sessions", rl_api.hip) -------------------------------------------------------
@@ -511,10 +511,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // FUSED: paths that end on a light are splatted into `plot` (photons unused); otherwise every path's
 // MappedPhoton goes to `photons` (plot unused).  A compile-time switch so neither variant carries the
 // other's code and registers.
-// MULTI: the launch carries several render calls (job table); a compile-time switch so that a single call's launch
-// -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
-// OPEN (implies MULTI): the job table is RlOpenDev::jobs and grows while the kernel runs (see above).
-template <bool STAGE_LDS, bool FUSED, bool MULTI, bool OPEN>
+// OPEN: an open launch (see RlOpenDev above): the paths come from a job table that grows while the kernel runs, every lane
+// remembers which job its path belongs to, and finished paths are counted per job.  A compile-time switch so that a
+// plain launch -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
+template <bool STAGE_LDS, bool FUSED, bool OPEN>
 // At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
 // the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             const float sx = emit[0 * 128 + slot], sy = emit[1 * 128 + slot], wavelength = emit[2 * 128 + slot];
             const uint32_t tagged = rl_f2u(emit[4 * 128 + slot]);
             float* target = plot;
-            if (MULTI) target = (float*)jobs[tagged >> 24].target;
-            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, MULTI ? (tagged & 0xffffffu) : tagged);
+            if (OPEN) target = (float*)jobs[tagged >> 24].target;
+            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
                 const RlSplat sp = rl_splat_weights(job.width, job.height, job.aspect_ratio, sx, sy);
@@ -788,14 +788,14 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                         }
                         // Nothing new.  While calls of this launch are still finishing their last paths the kernel is
                         // running anyway, and their callers come back with the next batch the moment they are told: stay
-                        // open until every call is complete and then for a grace period (job.reserved ticks of 10 ns).
+                        // open until every call is complete and then for a grace period (job.grace_ticks).
                         uint32_t stay = 0;
                         if (lane == 0 && known_local < RL_OPEN_CAP) {
                             const bool finishing = __hip_atomic_load(&od->completed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < known_local;
                             const unsigned long long now = wall_clock64(), since = finishing ? od->stuck_since : od->idle_since;
                             // (a call that never completes would be a bug in the counting above: after 5 s without one
                             // the launch ends regardless, and the host reports the call that is missing)
-                            const unsigned long long limit = finishing ? 500000000ull : (unsigned long long)job.reserved;
+                            const unsigned long long limit = finishing ? 500000000ull : (unsigned long long)job.grace_ticks;
                             if (since == 0) (finishing ? od->stuck_since : od->idle_since) = now, stay = 1;
                             else if (now - since < limit) stay = 1;
                             if (!finishing) od->stuck_since = 0;
@@ -838,10 +838,6 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                     chunk_end = chunk_next + chunk;
                 }
                 RL_STAT(RL_ST_REFILLS, 1);
-                if (MULTI && !OPEN) { // all 64 offsets of a refill lie in one call; a wave's offsets only grow
-                    while (stash_job + 1u < job.n_jobs && chunk_next >= jobs[stash_job].end) stash_job += 1u;
-                    stash_first = jobs[stash_job].first_path - jobs[stash_job].start;
-                }
                 if (OPEN) stash_first = jobs[stash_job].first_path;
                 const uint64_t offset = chunk_next + lane;
                 chunk_next += 64;
@@ -876,7 +872,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                 const uint32_t lo = stash_off[slot], hi = stash_off[64 + slot];
                 if ((lo & hi) != 0xffffffffu) {
                     my_path = ((uint64_t)hi << 32) | lo;
-                    if (MULTI) my_job = stash_job;
+                    if (OPEN) my_job = stash_job;
                     p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
                     p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
                     p.wavelength = stash[6 * 64 + slot];
@@ -958,15 +954,12 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                         __hip_atomic_store(dst + 1, rl_f2u(ph.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(dst + 2, rl_f2u(ph.probability), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         __hip_atomic_store(dst + 3, rl_f2u(ph.wavelength), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else if (MULTI) {
-                        const RlJobEntry e = jobs[my_job];
-                        ((RlMappedPhoton*)e.target)[my_path - e.first_path] = ph;
                     } else {
                         photons[my_path - job.first_path] = ph;
                     }
                 } else {
                     ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
-                    emit_obj = MULTI ? (emitter | (my_job << 24)) : emitter; // merged launches: the call, i.e. the plot buffer
+                    emit_obj = OPEN ? (emitter | (my_job << 24)) : emitter; // open launches: the call, i.e. the plot buffer
                 }
                 if (OPEN) { // trace_unit.rs:92-131: the Void and a light end the path in the scan's iteration, roulette after the bounce
                     ended_now = true;

@@ -218,10 +218,10 @@ def test_bench_runs_its_own_two_ranks_on_one_gpu():
     assert line["value"] > 0 and "cpu_baseline" not in line
 
 
-def test_concurrent_renders_are_merged_into_one_launch_and_stay_bit_exact(R):
-    """The reference runs one TraceUnit::render per worker thread (app.rs:92-134).  Calls in flight together are
-    merged into one launch by the library (rl_api.hip's batcher); every unit must still receive exactly its own
-    paths: photons bit-equal to the oracle's for that unit's path range, whatever was merged with whatever."""
+def test_concurrent_renders_share_open_launches_and_stay_bit_exact(R):
+    """The reference runs one TraceUnit::render per worker thread (app.rs:92-134).  The library appends such calls to
+    a trace kernel that is already running (open launches, rl_api.hip); every unit must still receive exactly its own
+    paths: photons bit-equal to the oracle's for that unit's path range, whatever shared a launch with whatever."""
     import threading
     W, H = 160, 90
     objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
@@ -246,21 +246,19 @@ def test_concurrent_renders_are_merged_into_one_launch_and_stay_bit_exact(R):
         [t.start() for t in threads]
         [t.join() for t in threads]
         assert not errors, errors
-        total_segments = 0
+        segments = [0] * workers
         for (i, rnd), (first, got) in results.items():
             want, segs = oscene.render(W, H, 6, 2, first, n, threads=4)
             assert got.tobytes() == want.tobytes(), (n, i, rnd)
-            total_segments += segs
-        stats = [u.stats() for u in units]
-        assert sum(s[0] for s in stats) == 3 * workers * n and sum(s[1] for s in stats) == total_segments
-        launches = sum(1 for s in stats if s[2] > 0)
-        if n % 256 == 0:
-            assert launches <= workers        # merged launches are accounted to the unit that led them
+            segments[i] += segs
+        stats = [u.stats() for u in units]       # paths and segments are counted per call, so per unit
+        assert [s[0] for s in stats] == [3 * n] * workers and [s[1] for s in stats] == segments
+        assert sum(s[2] for s in stats) > 0      # kernel time: credited to whichever unit asked first
 
 
-def test_concurrent_fused_renders_share_a_launch_and_hit_their_own_plot_units(R):
-    """rl_trace_unit_render_fused_sync from several threads: one launch splats into every caller's plot unit
-    (job table in the kernel); each buffer must equal the oracle's plot of that caller's path range."""
+def test_concurrent_fused_renders_share_open_launches_and_hit_their_own_plot_units(R):
+    """rl_trace_unit_render_fused_sync from several threads: the kernel they share splats into every caller's own plot
+    unit (job table in the kernel); each buffer must equal the oracle's plot of that caller's path range."""
     import threading
     W, H, workers = 96, 54, 6
     objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
@@ -291,6 +289,102 @@ def test_concurrent_fused_renders_share_a_launch_and_hit_their_own_plot_units(R)
         segs += s
         want = O.plot(W, H, photons)
         assert np.allclose(plots[i].tristimulus_buffer, want, rtol=2e-5, atol=1e-7), i
-    assert sum(u.stats()[1] for u in units) == segs and sum(u.stats()[0] for u in units) == sum(sizes)
+    assert sum(u.stats()[1] for u in units) == segs and [u.stats()[0] for u in units] == sizes
     after = R.batch_histogram()
-    assert sum(k * (after.get(k, 0) - before.get(k, 0)) for k in after) == workers      # every call went through the batcher
+    assert sum(k * (after.get(k, 0) - before.get(k, 0)) for k in after) == workers - 1   # all but the ragged one were appended
+
+
+def test_an_open_launch_rolls_over_when_its_job_table_is_full(R):
+    """More blocking calls than one kernel's job table holds (256), from four threads without a pause: the launch that
+    is full closes, the next call starts another one, nothing is lost or traced twice."""
+    import threading
+    W, H, n, workers, rounds = 64, 36, 256, 4, 120
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    units = [R.TraceUnit(i, W, H, n_photons=n) for i in range(workers)]
+    kept, errors = {}, []
+    before = R.batch_histogram()
+
+    def work(i):
+        try:
+            for rnd in range(rounds):
+                first = (rnd * workers + i) * n
+                units[i].render(scene, seed=11, stream=0, first_path_index=first)
+                if rnd % 17 == 0 or rnd == rounds - 1:
+                    kept[(i, rnd)] = (first, units[i].mapped_photons)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for (i, rnd), (first, got) in kept.items():
+        want, _ = oscene.render(W, H, 11, 0, first, n, threads=2)
+        assert got.tobytes() == want.tobytes(), (i, rnd)
+    _, segs = oscene.render(W, H, 11, 0, 0, workers * rounds * n, threads=8)     # the calls tile [0, workers * rounds * n)
+    stats = [u.stats() for u in units]
+    assert [s[0] for s in stats] == [rounds * n] * workers and sum(s[1] for s in stats) == segs
+    after = R.batch_histogram()
+    carried = {k: after.get(k, 0) - before.get(k, 0) for k in after if after.get(k, 0) != before.get(k, 0)}
+    assert sum(k * v for k, v in carried.items()) == workers * rounds and max(carried) <= 256
+
+
+def test_calls_with_different_parameters_get_launches_of_their_own(R):
+    """Two scenes, two seeds, two image sizes at the same time: only calls that agree in all of them may share a kernel
+    (it holds one scene and one RlTraceJob); each result is still the oracle's."""
+    import threading
+    n = 1 << 12
+    cases = []
+    for k, (which, seed, (W, H)) in enumerate([(R.SCENE_DEMO, 3, (64, 36)), (R.SCENE_GLASS_STRESS, 3, (64, 36)), (R.SCENE_DEMO, 4, (64, 36)),
+                                               (R.SCENE_DEMO, 3, (80, 45)), (R.SCENE_GLASS_STRESS, 9, (48, 27)), (R.SCENE_DEMO, 3, (64, 36))]):
+        objs, cam = R.builtin_scene_desc(which)
+        cases.append((objs, cam, R.Scene(objs, cam), seed, W, H, R.TraceUnit(k, W, H, n_photons=n)))
+    got, errors = {}, []
+
+    def work(k):
+        try:
+            for rnd in range(4):
+                _, _, scene, seed, W, H, unit = cases[k]
+                unit.render(scene, seed=seed, stream=1, first_path_index=rnd * n + k)
+                got[(k, rnd)] = unit.mapped_photons
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(cases))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for (k, rnd), photons in got.items():
+        objs, cam, _, seed, W, H, _ = cases[k]
+        want, _ = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam)).render(W, H, seed, 1, rnd * n + k, n, threads=2)
+        assert photons.tobytes() == want.tobytes(), (k, rnd)
+
+
+def test_small_kernels_run_beside_a_resident_trace_kernel(R):
+    """An open launch keeps every CU occupied for as long as calls keep coming; PlotUnit::plot, GatherUnit::accumulate
+    and the clears must not queue up behind it.  They run beside it because the trace kernel leaves them registers
+    (<= 120 of the 128 VGPRs a wave may have at four waves per SIMD) and has a hardware queue of its own."""
+    import threading
+    import time
+    W, H = 1280, 720
+    scene = R.Scene.builtin()
+    big, other = R.TraceUnit(0, W, H), R.TraceUnit(1, W, H)
+    pa, pb, g = R.PlotUnit(0, W, H), R.PlotUnit(1, W, H), R.GatherUnit(W, H)
+    n = 64 * 524288                                          # ~8.5 ms of tracing
+    big.render_fused_sync(scene, pa, n)
+    other.render(scene)
+    pb.plot([other]); pb.sync(); g.accumulate(pb); g.sync()  # warm-up
+    best = None
+    for _ in range(3):
+        th = threading.Thread(target=lambda: big.render_fused_sync(scene, pa, n))
+        t0 = time.perf_counter()
+        th.start()
+        time.sleep(0.002)
+        pb.plot([other]); pb.sync(); g.accumulate(pb); g.sync()
+        small_done = time.perf_counter() - t0
+        th.join()
+        trace_done = time.perf_counter() - t0
+        best = (small_done, trace_done) if best is None or small_done / trace_done < best[0] / best[1] else best
+    assert best[0] < 0.6 * best[1], best     # measured: done at 3.3 ms of 8.6 (2 ms of it the sleep above)

@@ -23,9 +23,9 @@ for fused in (False, True):
         rgb, st = R.app_run(1280, 720, 4096, concurrency=c, photons_per_batch=524288, fused=fused, verbose=False)
         print("fused" if fused else "un-fused", "workers", c, round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6),
               "Mrays/s", round(st["paths"] / 524288 / st["seconds"]), "batches/s", st["tasks"], flush=True)
-print("merged TraceUnit::render launches so far, {calls per launch: launches}:", R.batch_histogram())
+print("open launches so far, {calls carried: launches}:", R.batch_histogram())
 rgb, st = R.app_run(1280, 720, 4096, concurrency=8, photons_per_batch=524288, fused=False, queued_trace=True, verbose=False)
-print("un-fused workers 8, queued (not merged) trace tasks", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
+print("un-fused workers 8, queued trace tasks (one launch per batch, nobody waits)", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
 for fused in (False, True):
     rgb, st = R.app_run(1280, 720, 96, concurrency=2, photons_per_batch=64 * 524288, fused=fused, verbose=False)
     print("fused" if fused else "un-fused", "64-batch tasks, workers 2", round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
