@@ -488,6 +488,9 @@ struct Session {
     bool open = false;     // the host may still try to append
     uint32_t n = 0;        // jobs appended so far
     int waiters = 0;       // calls that have not yet read their completion flag (ctl must not be recycled under them)
+    const void* tuned_kernel = nullptr; // launch configuration last set up for this slot
+    size_t tuned_dyn = 0;
+    int tuned_per_cu = 1;
     const RlScene* scene = nullptr;
     uint64_t seed = 0;
     uint32_t stream_id = 0, width = 0, height = 0;
@@ -588,10 +591,15 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)
                         : (fused ? rl_trace_kernel<false, true, true> : rl_trace_kernel<false, false, true>);
     const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
-    RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    int per_cu = 1;
-    RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
-    if (per_cu < 1) per_cu = 1;
+    if (x.tuned_kernel != (const void*)kernel || x.tuned_dyn != dyn) { // once per (slot, variant, scene size)
+        RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        int n = 1;
+        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, RL_TRACE_BLOCK, dyn));
+        x.tuned_per_cu = n < 1 ? 1 : n;
+        x.tuned_kernel = (const void*)kernel;
+        x.tuned_dyn = dyn;
+    }
+    const int per_cu = x.tuned_per_cu;
     std::memset(x.ctl, 0, sizeof(RlOpenCtl));
     x.ctl->jobs[0] = first;
     x.ctl->closed_at = RL_OPEN_NONE;

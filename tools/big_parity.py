@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off large-sample parity run on a GPU box: N million photons, GPU (C ABI) vs CPU oracle, bitwise.
+"""One-off large-sample parity run on a GPU box: N million photons, GPU (C ABI) vs CPU oracle, bitwise; the chunks
+alternate between the two kernel variants (open launch / plain launch).
 Usage: python tools/big_parity.py [millions=32] [scene=demo|glass|replicated]"""
 import os
 import sys
@@ -31,7 +32,11 @@ except Exception:
 bad_total, segs_total, t0 = 0, 0, time.time()
 for k in range(millions):
     first = 7_000_000_000 + k * N
-    t.render(scene, seed=11, stream=k % 5, first_path_index=first)
+    if k % 2 == 0:   # the blocking call: an open launch (rl_trace_unit_render)
+        t.render(scene, seed=11, stream=k % 5, first_path_index=first)
+    else:            # a plain launch of its own (rl_trace_unit_render_async + sync)
+        t.render_async(scene, seed=11, stream=k % 5, first_path_index=first)
+        t.sync()
     got = t.mapped_photons
     want, segs = oscene.render(1920, 1080, 11, k % 5, first, N, threads=threads)
     segs_total += segs

@@ -41,7 +41,11 @@ for k in range(scenes):
     for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
         t = R.TraceUnit(0, 640, 360, n_photons=N)
         t.set_fetch(fetch)
-        t.render(scene, seed=1000 + k, stream=k % 7, first_path_index=10_000_000 * k)
+        if k % 2 == 0:   # an open launch (the blocking call) / a plain launch of its own: the two kernel variants
+            t.render(scene, seed=1000 + k, stream=k % 7, first_path_index=10_000_000 * k)
+        else:
+            t.render_async(scene, seed=1000 + k, stream=k % 7, first_path_index=10_000_000 * k)
+            t.sync()
         if t.mapped_photons.tobytes() != want.tobytes() or t.stats()[1] != segs:
             bad += 1
             print("MISMATCH scene", k, "spheres", n_spheres, "prisms", n_prisms, "fetch", fetch)
