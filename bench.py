@@ -197,6 +197,18 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
                                      "frac": achieved / PEAK_FP32_VECTOR_TFLOPS}}
 
 
+def measure_app(R, fused, workers, device, batches=2048):
+    """The drop-in at the reference's own task size: rl_app_run (TaskScheduler + worker pool, csrc/rl_app.cpp) with Trace
+    tasks of 524,288 paths (trace_unit.rs:67) and as many workers as the host has cores (app.rs:55), at 1280x720."""
+    rgb, st = R.app_run(1280, 720, batches, concurrency=workers, photons_per_batch=BATCH, fused=fused, verbose=False, device=device)
+    return {"config": "app-720p-%s" % ("fused" if fused else "unfused"),
+            "workload": "rl_app_run: built-in demo scene, 1280x720, %d batches of %d paths through the scheduler's Trace / Plot / Gather "
+                        "tasks, %d workers, %s; includes the final tonemap"
+                        % (batches, BATCH, workers, "Trace + Plot fused at plot time" if fused else "separate Trace and Plot tasks as in the reference"),
+            "value": st["segments"] / st["seconds"] / 1e6, "unit": "Mrays/s", "mpaths_per_s": st["paths"] / st["seconds"] / 1e6,
+            "batches_per_s": st["paths"] / BATCH / st["seconds"], "workers": workers, "seconds": st["seconds"]}
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (the same environment contract
     torch.distributed.run sets up), relay rank 0's JSON line."""
@@ -371,6 +383,8 @@ def main():
         }
         if world == 1 and not args.no_others:
             out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]
+            workers = max(1, min(usable_cores(), 85))
+            out["config"]["others"] += [measure_app(R, fused, workers, device) for fused in (False, True)]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, cam, W, H)
         print(json.dumps(out), flush=True)

@@ -56,11 +56,15 @@ extern "C" {
     pub fn rl_trace_unit_destroy(u: *mut RlTraceUnit) -> c_int;
     pub fn rl_trace_unit_set_fetch(u: *mut RlTraceUnit, primitive_fetch: c_int) -> c_int;   // 0 LDS, 1 global
     pub fn rl_trace_unit_render(u: *mut RlTraceUnit, scene: *const RlScene, seed: u64, stream: u32, first_path: u64) -> c_int;
+    pub fn rl_trace_unit_render_begin(u: *mut RlTraceUnit, scene: *const RlScene, seed: u64, stream: u32, first_path: u64) -> c_int;
+    pub fn rl_trace_unit_render_end(u: *mut RlTraceUnit) -> c_int;
     pub fn rl_trace_unit_render_async(u: *mut RlTraceUnit, scene: *const RlScene, seed: u64, stream: u32, first_path: u64) -> c_int;
     pub fn rl_trace_unit_render_fused(u: *mut RlTraceUnit, scene: *const RlScene, plot: *mut RlPlotUnit,
                                       seed: u64, stream: u32, first_path: u64, n_paths: u64) -> c_int;
     pub fn rl_trace_unit_render_fused_sync(u: *mut RlTraceUnit, scene: *const RlScene, plot: *mut RlPlotUnit,
                                            seed: u64, stream: u32, first_path: u64, n_paths: u64) -> c_int;
+    pub fn rl_trace_unit_render_fused_begin(u: *mut RlTraceUnit, scene: *const RlScene, plot: *mut RlPlotUnit,
+                                            seed: u64, stream: u32, first_path: u64, n_paths: u64) -> c_int;
     pub fn rl_trace_unit_sync(u: *mut RlTraceUnit) -> c_int;
     pub fn rl_trace_unit_photons(u: *mut RlTraceUnit, out: *mut RlMappedPhoton) -> c_int;
     pub fn rl_trace_unit_stats(u: *mut RlTraceUnit, paths: *mut u64, segments: *mut u64, kernel_ms: *mut c_double) -> c_int;

@@ -161,6 +161,13 @@ int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
  * call; the kernel time of an open launch is credited to the first of its units asked for rl_trace_unit_stats. */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
+/* rl_trace_unit_render in two halves, for a host thread that feeds several GPUs (rl_app_run with n_devices > 1 does):
+ * _begin appends the call to the device's open launch (or starts one) and returns at once, _end waits until the
+ * call's paths are finished (a no-op without a begun render).  One begun render per unit at a time; mapped_photons
+ * must not be plotted or read between the two.  rl_trace_unit_sync and rl_trace_unit_destroy end a begun render. */
+int rl_trace_unit_render_begin(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
+                               uint64_t first_path_index);
+int rl_trace_unit_render_end(RlTraceUnit* unit);
 /* The same without the final wait: the launch is queued on the unit's stream and rl_trace_unit_sync() (or
  * rl_plot_unit_plot, which orders itself after it on the device) completes it.  Lets one host thread start the
  * same task on several GPUs before waiting for any of them. */
@@ -179,6 +186,9 @@ int rl_trace_unit_render_fused(RlTraceUnit* unit, const RlScene* scene, RlPlotUn
  * the order of the float atomics. */
 int rl_trace_unit_render_fused_sync(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                     uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
+/* Its first half; rl_trace_unit_render_end is the second.  `plot` must not be gathered or read in between. */
+int rl_trace_unit_render_fused_begin(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
+                                     uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
 int rl_trace_unit_sync(RlTraceUnit* unit);
 /* Copies mapped_photons (trace_unit.rs:56) to host memory; `out` holds n_photons entries. */
 int rl_trace_unit_photons(RlTraceUnit* unit, RlMappedPhoton* out);

@@ -118,6 +118,16 @@ class TraceUnit(_Handle):
     def render(self, scene, seed=1, stream=0, first_path_index=0):
         check(lib.rl_trace_unit_render(self._h, scene.handle, seed, stream, first_path_index))
 
+    def render_begin(self, scene, seed=1, stream=0, first_path_index=0):
+        """First half of render(): the call is appended to the device's open launch; render_end() waits for it."""
+        check(lib.rl_trace_unit_render_begin(self._h, scene.handle, seed, stream, first_path_index))
+
+    def render_fused_begin(self, scene, plot_unit, n_paths, seed=1, stream=0, first_path_index=0):
+        check(lib.rl_trace_unit_render_fused_begin(self._h, scene.handle, plot_unit.handle, seed, stream, first_path_index, n_paths))
+
+    def render_end(self):
+        check(lib.rl_trace_unit_render_end(self._h))
+
     def render_async(self, scene, seed=1, stream=0, first_path_index=0):
         check(lib.rl_trace_unit_render_async(self._h, scene.handle, seed, stream, first_path_index))
 

@@ -80,9 +80,12 @@ SIGNATURES = {
     "rl_trace_unit_destroy": (_i, [_vp]),
     "rl_trace_unit_set_fetch": (_i, [_vp, _i]),
     "rl_trace_unit_render": (_i, [_vp, _vp, _u64, _u32, _u64]),
+    "rl_trace_unit_render_begin": (_i, [_vp, _vp, _u64, _u32, _u64]),
+    "rl_trace_unit_render_end": (_i, [_vp]),
     "rl_trace_unit_render_async": (_i, [_vp, _vp, _u64, _u32, _u64]),
     "rl_trace_unit_render_fused": (_i, [_vp, _vp, _vp, _u64, _u32, _u64, _u64]),
     "rl_trace_unit_render_fused_sync": (_i, [_vp, _vp, _vp, _u64, _u32, _u64, _u64]),
+    "rl_trace_unit_render_fused_begin": (_i, [_vp, _vp, _vp, _u64, _u32, _u64, _u64]),
     "rl_trace_unit_sync": (_i, [_vp]),
     "rl_trace_unit_photons": (_i, [_vp, _vp]),
     "rl_trace_unit_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(C.c_double)]),

@@ -79,6 +79,10 @@ struct RlScene {
     size_t staged_bytes;
 };
 
+namespace {
+struct Session;
+}
+
 struct RlTraceUnit {
     int device;
     uint32_t id, width, height, n_photons;
@@ -95,6 +99,12 @@ struct RlTraceUnit {
     bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
     uint64_t session_paths = 0, session_segments = 0; // of this unit's calls that open launches served
+    // a render that was begun and not yet ended (rl_trace_unit_render_begin / _end)
+    Session* ticket_session = nullptr; // the open launch it was appended to (null: a plain launch on `stream`, or none)
+    uint32_t ticket_job = 0;
+    uint64_t ticket_paths = 0;
+    bool ticket_unfused = false, ticket_pending = false;
+    double ticket_presync_us = 0.0, ticket_admit_us = 0.0;
 };
 
 struct RlPlotUnit {
@@ -374,6 +384,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
 
 namespace {
 int sessions_quiesce(int device, double* ms);
+int render_end(RlTraceUnit* u);
 }
 
 int rl_scene_destroy(RlScene* scene) {
@@ -435,6 +446,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
 int rl_trace_unit_destroy(RlTraceUnit* u) {
     if (!u) return RL_OK;
     (void)hipSetDevice(u->device);
+    (void)render_end(u); // a render that was begun writes to this unit's photons until it is complete
     if (u->stream) (void)hipStreamSynchronize(u->stream);
     for (EventPair& ep : u->pending) {
         (void)hipEventDestroy(ep.start);
@@ -659,8 +671,10 @@ int session_wait(Session& x, uint32_t k) {
     }
 }
 
-int render_session(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream_id, uint64_t first_path_index,
-                   uint64_t n_paths) {
+// First half of a blocking render served by an open launch: appends the call (or starts a launch with it) and leaves a
+// ticket in the unit.
+int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream_id, uint64_t first_path_index,
+                  uint64_t n_paths) {
     // What the call's target is still being read or cleared by (a plot of the unit's previous photons, the gather's
     // clear of the plot buffer) must be over before a kernel that is already running may write to it.
     const auto t0 = std::chrono::steady_clock::now();
@@ -701,23 +715,35 @@ int render_session(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint6
                     break;
                 }
             if (mine) break;
-            bool retry = false; // an open session that is full or serves other parameters: close it to the host
+            bool retry = false; // an open session that is full: close it to the host
             for (Session& x : d->s)
                 if (x.open && x.n >= RL_OPEN_CAP) x.open = false, retry = true;
             if (!retry) d->changed.wait_for(guard, std::chrono::microseconds(50));
         }
     }
-#ifdef RL_OPEN_DEBUG
-    const auto t_app = std::chrono::steady_clock::now();
-#endif
+    u->ticket_session = mine;
+    u->ticket_job = (uint32_t)k;
+    u->ticket_paths = n_paths;
+    u->ticket_unfused = plot == nullptr;
+    u->ticket_pending = true;
+    u->ticket_presync_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    u->ticket_admit_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    return RL_OK;
+}
+
+// Second half: waits until the call's paths are finished.
+int session_end(RlTraceUnit* u) {
+    Session* mine = u->ticket_session;
+    const uint32_t k = u->ticket_job;
+    DeviceSessions* d = sessions_of(u->device);
     const auto t2 = std::chrono::steady_clock::now();
-    int rc = session_wait(*mine, (uint32_t)k);
+    int rc = session_wait(*mine, k);
 #ifdef RL_OPEN_DEBUG
     {
-        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_app).count();
+        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count();
         const RlOpenCtl* c = mine->ctl;
         if (k >= 100 && k < 140)
-            fprintf(stderr, "job %d: host append->done %.0f us | gpu (us since job 100 known): known %.1f first %.1f last %.1f done %.1f\n", k, host_us,
+            fprintf(stderr, "job %u: host wait %.0f us | gpu (us since job 100 known): known %.1f first %.1f last %.1f done %.1f\n", k, host_us,
                     (double)(long long)(c->t_known[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_first[k] - c->t_known[100]) / 100.0,
                     (double)(long long)(c->t_last[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_done[k] - c->t_known[100]) / 100.0);
     }
@@ -727,33 +753,47 @@ int render_session(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint6
         const auto t3 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> guard(d->lock);
         mine->waiters -= 1;
-        d->presync_us += std::chrono::duration<double, std::micro>(t1 - t0).count();
-        d->admit_us += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        d->presync_us += u->ticket_presync_us;
+        d->admit_us += u->ticket_admit_us;
         d->wait_us += std::chrono::duration<double, std::micro>(t3 - t2).count();
         d->calls += 1;
     }
+    u->ticket_session = nullptr;
+    u->ticket_pending = false;
     if (rc != RL_OK) return rc;
-    u->session_paths += n_paths;
+    u->session_paths += u->ticket_paths;
     u->session_segments += job_segments;
-    if (!plot) RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
+    if (u->ticket_unfused) RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
     return RL_OK;
 }
 
 #define RL_SESSION_MAX_PATHS (1ull << 28) // per call: its segment count must fit 32 bits
 
-// The blocking render of both kinds: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
-int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream, uint64_t first_path_index,
-                    uint64_t n_paths) {
+// The two halves of the blocking render of both kinds: un-fused (plot == nullptr, n_paths = the unit's batch) and fused.
+int render_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream, uint64_t first_path_index,
+                 uint64_t n_paths) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if (u->ticket_pending) return fail(RL_E_STATE, "the trace unit has a render that was begun and not ended");
     if (n_paths == 0) return RL_OK;
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     if (first_path_index + n_paths < first_path_index || first_path_index + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
-    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return render_session(u, scene, plot, seed, stream, first_path_index, n_paths);
-    // a ragged or a huge batch: a launch of its own
+    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+    // a ragged or a huge batch: a launch of its own on the unit's stream
     rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
     if (rc != RL_OK) return rc;
+    u->ticket_session = nullptr;
+    u->ticket_pending = true;
+    return RL_OK;
+}
+
+int render_end(RlTraceUnit* u) {
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    if (!u->ticket_pending) return RL_OK;
+    if (u->ticket_session) return session_end(u);
+    u->ticket_pending = false;
     RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
@@ -766,17 +806,41 @@ int render_blocking(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint
 // Results are those of separate launches, bit for bit: a path is a pure function of (seed, stream, path index).
 int rl_trace_unit_render(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
     if (!u || !scene) return fail(RL_E_INVALID, "null handle");
-    return render_blocking(u, scene, nullptr, seed, stream, first_path_index, u->n_photons);
+    const int rc = render_begin(u, scene, nullptr, seed, stream, first_path_index, u->n_photons);
+    return rc != RL_OK ? rc : render_end(u);
 }
 
-int rl_trace_unit_render_fused_sync(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
-                                    uint64_t first_path_index, uint64_t n_paths) {
+int rl_trace_unit_render_begin(RlTraceUnit* u, const RlScene* scene, uint64_t seed, uint32_t stream, uint64_t first_path_index) {
+    if (!u || !scene) return fail(RL_E_INVALID, "null handle");
+    return render_begin(u, scene, nullptr, seed, stream, first_path_index, u->n_photons);
+}
+
+int rl_trace_unit_render_end(RlTraceUnit* u) {
+    if (!u) return fail(RL_E_INVALID, "null trace unit");
+    return render_end(u);
+}
+
+namespace {
+int check_fused(const RlTraceUnit* u, const RlScene* scene, const RlPlotUnit* plot) {
     if (!u || !scene || !plot) return fail(RL_E_INVALID, "null handle");
     if (plot->device != u->device || plot->width != u->width || plot->height != u->height)
         return fail(RL_E_STATE, "plot unit does not match the trace unit (device or size)");
-    return render_blocking(u, scene, plot, seed, stream, first_path_index, n_paths);
+    return RL_OK;
+}
+} // namespace
+
+int rl_trace_unit_render_fused_sync(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
+                                    uint64_t first_path_index, uint64_t n_paths) {
+    int rc = check_fused(u, scene, plot);
+    if (rc == RL_OK) rc = render_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+    return rc != RL_OK ? rc : render_end(u);
 }
 
+int rl_trace_unit_render_fused_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
+                                     uint64_t first_path_index, uint64_t n_paths) {
+    const int rc = check_fused(u, scene, plot);
+    return rc != RL_OK ? rc : render_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+}
 
 int rl_trace_unit_render_fused(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
                                uint64_t first_path_index, uint64_t n_paths) {
@@ -790,7 +854,7 @@ int rl_trace_unit_render_fused(RlTraceUnit* u, const RlScene* scene, RlPlotUnit*
 
 int rl_trace_unit_sync(RlTraceUnit* u) {
     if (!u) return fail(RL_E_INVALID, "null trace unit");
-    int rc = use_device(u->device);
+    int rc = render_end(u); // also ends a render that was begun
     if (rc != RL_OK) return rc;
     RL_HIP(hipStreamSynchronize(u->stream));
     return drain_events(u);

@@ -47,6 +47,7 @@ struct AppState {
     RlScheduler* scheduler = nullptr;
     std::vector<Rank> ranks;
     bool use_rccl = false;     // more than one distinct device
+    bool distinct_devices = true; // no device is listed twice
     RlGatherUnit* gather = nullptr;   // on rank 0's device
     RlTonemapUnit* tonemap = nullptr; // on rank 0's device
     uint64_t first_batch = 0;
@@ -191,22 +192,27 @@ void execute_task(AppState& a, const RlTask& task) {
     case RL_TASK_TRACE: // app.rs:132-134, on every rank at once
         if (!c.fused) {
             // Default: the blocking rl_trace_unit_render, like a reference worker -- the workers' calls share open
-            // launches on the device (measured: 11.3 Grays/s at 8 workers against 6.8 for queueing every batch as its
-            // own launch and moving on, RlAppConfig::queued_trace).
-            // With several ranks one launch per batch is started on every device before any is waited for.
-            const bool shared_blocking = !c.queued_trace && a.ranks.size() == 1;
+            // launches on their device (measured: 11.3 Grays/s at 8 workers against 6.8 for queueing every batch as its
+            // own launch and moving on, RlAppConfig::queued_trace) -- in its two halves, so that with several ranks the
+            // call is begun on every device before any is waited for.  Ranks that share a device (a test layout) would
+            // only take turns at it with their open launches (one kernel serves one RNG stream): they get a launch per
+            // batch each instead.
+            const bool open_launches = !c.queued_trace && a.distinct_devices;
             for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
                 RlTraceUnit* u = a.ranks[r].trace_units[task.unit];
-                if (shared_blocking) {
-                    rc = rl_trace_unit_render(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
+                if (open_launches) {
+                    rc = rl_trace_unit_render_begin(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 } else {
                     rc = rl_trace_unit_sync(u); // back-pressure: this unit's previous launch (long finished, normally)
                     if (rc == RL_OK)
                         rc = rl_trace_unit_render_async(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 }
             }
-            if (!shared_blocking && !c.queued_trace)
-                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
+            if (!c.queued_trace)
+                for (size_t r = 0; r < a.ranks.size(); ++r) { // every begun call is ended, also after an error
+                    const int rc_end = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
+                    if (rc == RL_OK) rc = rc_end;
+                }
         }
         // fused: the photons are produced when the unit is plotted (the target buffer is known then)
         break;
@@ -226,21 +232,24 @@ void execute_task(AppState& a, const RlTask& task) {
             if (task.n_units != 0) {
                 const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
                 const uint64_t first = a.fused_next_path.fetch_add(n);
-                if (!c.queued_trace && a.ranks.size() == 1) {
-                    // the blocking call: the workers' Plot tasks share open launches on the device
-                    rc = rl_trace_unit_render_fused_sync(a.ranks[0].trace_units[task.units[0]], a.ranks[0].scene, a.ranks[0].plot_units[task.unit],
-                                                         c.seed, c.stream, first, n);
-                } else {
-                    for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
-                        RlTraceUnit* u = a.ranks[r].trace_units[task.units[0]];
+                const bool open_launches = !c.queued_trace && a.distinct_devices; // as for un-fused Trace tasks above
+                for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
+                    RlTraceUnit* u = a.ranks[r].trace_units[task.units[0]];
+                    if (open_launches) { // the workers' Plot tasks share open launches on their device
+                        rc = rl_trace_unit_render_fused_begin(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
+                                                              c.stream + (uint32_t)r, first, n);
+                    } else {
                         if (c.queued_trace) rc = rl_trace_unit_sync(u); // back-pressure only: this unit's previous launch
                         if (rc == RL_OK)
                             rc = rl_trace_unit_render_fused(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
                                                             c.stream + (uint32_t)r, first, n);
                     }
-                    if (!c.queued_trace)
-                        for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) rc = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
                 }
+                if (!c.queued_trace)
+                    for (size_t r = 0; r < a.ranks.size(); ++r) {
+                        const int rc_end = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
+                        if (rc == RL_OK) rc = rc_end;
+                    }
             }
         }
         break;
@@ -376,6 +385,7 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
         if (k.leader == (int)r) distinct.push_back(k.device);
     }
     a.use_rccl = distinct.size() > 1;
+    a.distinct_devices = distinct.size() == n_ranks;
     if (rc == RL_OK && a.use_rccl) {
         std::vector<RlComm*> comms(distinct.size(), nullptr);
         rc = rl_comm_init_all(distinct.data(), (int)distinct.size(), comms.data()); // rank 0's device is distinct[0] = comm rank 0

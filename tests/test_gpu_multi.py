@@ -388,3 +388,34 @@ def test_small_kernels_run_beside_a_resident_trace_kernel(R):
         trace_done = time.perf_counter() - t0
         best = (small_done, trace_done) if best is None or small_done / trace_done < best[0] / best[1] else best
     assert best[0] < 0.6 * best[1], best     # measured: done at 3.3 ms of 8.6 (2 ms of it the sleep above)
+
+
+def test_render_in_two_halves_begin_on_many_units_then_end(R):
+    """rl_trace_unit_render_begin / _end (what one host thread feeding several GPUs uses): calls begun back to back on
+    several units are all in flight in one open launch; ended in any order they hold exactly what render() gives."""
+    W, H, n = 96, 54, 1 << 12
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    units = [R.TraceUnit(i, W, H, n_photons=n) for i in range(5)]
+    plot = R.PlotUnit(0, W, H)
+    fused = R.TraceUnit(9, W, H, n_photons=64)
+    for i, u in enumerate(units):
+        u.render_begin(scene, seed=4, stream=3, first_path_index=1000 * i)
+    fused.render_fused_begin(scene, plot, 3 * n, seed=4, stream=3, first_path_index=77)
+    with pytest.raises(R.RlError):
+        units[0].render_begin(scene, seed=4, stream=3, first_path_index=0)       # one begun render per unit
+    for u in reversed(units):
+        u.render_end()
+    units[2].render_end()                                                       # nothing begun: a no-op
+    fused.sync()                                                                # sync ends a begun render too
+    for i, u in enumerate(units):
+        want, segs = oscene.render(W, H, 4, 3, 1000 * i, n, threads=2)
+        assert u.mapped_photons.tobytes() == want.tobytes() and u.stats()[:2] == (n, segs)
+    photons, segs = oscene.render(W, H, 4, 3, 77, 3 * n, threads=2)
+    assert np.allclose(plot.tristimulus_buffer, O.plot(W, H, photons), rtol=2e-5, atol=1e-7) and fused.stats()[:2] == (3 * n, segs)
+    ragged = R.TraceUnit(10, W, H, n_photons=1000)                               # not a multiple of 64: a launch of its own
+    ragged.render_begin(scene, seed=4, stream=3, first_path_index=5)
+    ragged.render_end()
+    want, _ = oscene.render(W, H, 4, 3, 5, 1000, threads=2)
+    assert ragged.mapped_photons.tobytes() == want.tobytes()
