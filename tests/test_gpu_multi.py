@@ -419,3 +419,42 @@ def test_render_in_two_halves_begin_on_many_units_then_end(R):
     ragged.render_end()
     want, _ = oscene.render(W, H, 4, 3, 5, 1000, threads=2)
     assert ragged.mapped_photons.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_results_of_a_call_are_visible_the_moment_it_returns(R, fused):
+    """The hazard of an open launch: a call returns while the kernel that produced its results is still running (the
+    other threads keep it busy), and the very next thing the caller does is launch a kernel that reads them -- the plot
+    of the photons, or the download of the splatted buffer.  Nothing may be missing: every (thread, round) is compared
+    with the oracle's plot of exactly that path range."""
+    import threading
+    W, H, n, workers, rounds = 48, 27, 1 << 11, 4, 40
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    units = [R.TraceUnit(i, W, H, n_photons=n) for i in range(workers)]
+    plots = [R.PlotUnit(i, W, H) for i in range(workers)]
+    got, errors = {}, []
+
+    def work(i):
+        try:
+            for rnd in range(rounds):
+                first = (rnd * workers + i) * n
+                if fused:
+                    units[i].render_fused_sync(scene, plots[i], n, seed=13, stream=0, first_path_index=first)
+                else:
+                    units[i].render(scene, seed=13, stream=0, first_path_index=first)
+                    plots[i].plot([units[i]])
+                got[(i, rnd)] = plots[i].tristimulus_buffer
+                plots[i].clear()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(workers)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for (i, rnd), xyz in sorted(got.items()):
+        photons, _ = oscene.render(W, H, 13, 0, (rnd * workers + i) * n, n, threads=2)
+        want = O.plot(W, H, photons)
+        assert np.allclose(xyz, want, rtol=2e-5, atol=1e-7), (i, rnd, float(np.abs(xyz - want).max()))

@@ -35,6 +35,7 @@ PY
 (echo '$ python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64   # two ranks share GPU 0'
  timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64) > $OUT/bench_2ranks_gloo.txt 2>&1
 (echo '$ python bench.py --gpus 1 --dist-backend rccl  (one rank; for comparison)'; timeout 300 python bench.py --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-others --no-cpu-baseline) >> $OUT/bench_2ranks_gloo.txt 2>&1
+timeout 300 python tools/open_launch_stress.py > $OUT/open_launch_stress.txt 2>&1
 timeout 900 tools/valu_mb > $OUT/valu_microbench.txt 2>&1
 cat $OUT/app.txt $OUT/big_parity.txt $OUT/image_parity.txt
 tail -12 gpurun_out/${TAG}_console.txt | cut -c1-400
