@@ -161,10 +161,11 @@ int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
  * call; the kernel time of an open launch is credited to the first of its units asked for rl_trace_unit_stats. */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
-/* rl_trace_unit_render in two halves, for a host thread that feeds several GPUs (rl_app_run with n_devices > 1 does):
- * _begin appends the call to the device's open launch (or starts one) and returns at once, _end waits until the
- * call's paths are finished (a no-op without a begun render).  One begun render per unit at a time; mapped_photons
- * must not be plotted or read between the two.  rl_trace_unit_sync and rl_trace_unit_destroy end a begun render. */
+/* rl_trace_unit_render in two halves, for a host thread that has something else to do meanwhile (feeding other GPUs,
+ * taking the next task: rl_app_run does both): _begin appends the call to the device's open launch (or starts one) and
+ * returns at once, _end waits until the call's paths are finished (a no-op without a begun render).  One begun render
+ * per unit at a time.  Everything that reads mapped_photons ends a begun render by itself: rl_plot_unit_plot (for the
+ * units it plots), rl_trace_unit_photons, rl_trace_unit_sync, rl_trace_unit_stats, rl_trace_unit_destroy. */
 int rl_trace_unit_render_begin(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                                uint64_t first_path_index);
 int rl_trace_unit_render_end(RlTraceUnit* unit);
@@ -186,7 +187,10 @@ int rl_trace_unit_render_fused(RlTraceUnit* unit, const RlScene* scene, RlPlotUn
  * the order of the float atomics. */
 int rl_trace_unit_render_fused_sync(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                     uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
-/* Its first half; rl_trace_unit_render_end is the second.  `plot` must not be gathered or read in between. */
+/* Its first half.  The begun render belongs to `plot` (the trace unit is free for the next call at once) and is ended
+ * by whatever uses the plot unit's buffer next: rl_gather_unit_accumulate / _allreduce, rl_plot_unit_reduce / _add /
+ * _plot / _clear / _sync / _download / _upload / _device_buffer / _destroy, another render begun into it -- or by
+ * rl_trace_unit_render_end / _sync / _destroy of the trace unit it was begun on. */
 int rl_trace_unit_render_fused_begin(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                      uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
 int rl_trace_unit_sync(RlTraceUnit* unit);
@@ -346,12 +350,11 @@ typedef struct RlAppConfig {
                                     unit is one unit per rank, rank r uses RNG stream `stream + r`, and Task::Gather
                                     sums the ranks' plot buffers onto rank 0 first (rl_plot_unit_reduce over xGMI for
                                     distinct GPUs, rl_plot_unit_add for ranks that share one) */
-    int queued_trace;            /* 0 (default): a worker waits for the paths its task asked for -- un-fused, a Trace task is the
-                                    blocking rl_trace_unit_render, like a reference worker, and the workers' calls share open
-                                    launches (see there); fused, a Plot task does the same with rl_trace_unit_render_fused_sync.  Non-zero: a
-                                    launch is queued and the worker moves on (the device orders Plot after Trace and Gather
-                                    after Plot by itself; a unit's previous launch is waited for before it is used again).
-                                    Measured slower un-fused, equal fused, at the reference's task size */
+    int blocking_trace;          /* 0 (default): a task BEGINS its render (rl_trace_unit_render_begin, un-fused in the Trace task;
+                                    rl_trace_unit_render_fused_begin, fused in the Plot task) and the worker moves on; the task
+                                    that uses the result next -- Plot resp. Gather -- ends it.  Non-zero: the task waits for its
+                                    own paths, like a reference worker that traces them itself (slower with few workers: the
+                                    device only ever has `concurrency` batches to work on) */
     const int* devices;          /* n_devices device indices, rank 0 first (gather, tonemap and output live there);
                                     NULL = device, device + 1, ...  A device may be listed more than once. */
 } RlAppConfig;

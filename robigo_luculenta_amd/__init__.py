@@ -354,7 +354,7 @@ class TaskScheduler(_Handle):
 
 def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_batch=NUMBER_OF_PHOTONS, seed=1, stream=0,
             scene=SCENE_DEMO, scene_param=0, tonemap_interval_ms=30000, fused=False, output_ppm=None, checkpoint=None,
-            resume=False, verbose=False, sleep_us=0, first_batch=0, devices=None, queued_trace=False):
+            resume=False, verbose=False, sleep_us=0, first_batch=0, devices=None, blocking_trace=False):
     """App::new + worker loops (app.rs:54-111) until `max_batches` trace tasks are done, on one GPU or, with
     `devices` = a list of device indices (repeats allowed), on one rank per entry with the plot buffers summed
     onto rank 0 at every gather.  Returns (rgb image as (H, W, 3) uint8, stats dict)."""
@@ -362,7 +362,7 @@ def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_bat
     cfg = RlAppConfig(width, height, device, concurrency, photons_per_batch, seed, stream, scene, scene_param, max_batches,
                       tonemap_interval_ms, int(fused), output_ppm.encode() if output_ppm else None,
                       checkpoint.encode() if checkpoint else None, int(resume), int(verbose), sleep_us, first_batch,
-                      len(devices) if devices else 0, int(queued_trace), dev_arr)
+                      len(devices) if devices else 0, int(blocking_trace), dev_arr)
     stats = RlAppStats()
     rgb = np.zeros((height, width, 3), dtype=np.uint8)
     check(lib.rl_app_run(C.byref(cfg), C.byref(stats), rgb.ctypes.data_as(C.c_void_p)))

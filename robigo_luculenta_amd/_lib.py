@@ -53,7 +53,7 @@ class RlAppConfig(C.Structure):
                 ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
                 ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
                 ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32),
-                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("queued_trace", C.c_int), ("devices", C.POINTER(C.c_int))]
+                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("blocking_trace", C.c_int), ("devices", C.POINTER(C.c_int))]
 
 
 class RlAppStats(C.Structure):

@@ -81,6 +81,18 @@ struct RlScene {
 
 namespace {
 struct Session;
+
+// A blocking render that was begun and not yet ended.  The ticket of an un-fused render lives in its trace unit (whose
+// photons it fills), that of a fused render in the PLOT unit it splats into: the trace unit only lends its image size
+// and fetch mode, and is free for the next call at once.
+struct Ticket {
+    bool pending = false;
+    Session* session = nullptr; // the open launch the call was appended to; null: a plain launch on owner->stream
+    uint32_t job = 0;
+    uint64_t paths = 0;
+    RlTraceUnit* owner = nullptr; // the trace unit the call was made on (its counters are credited)
+    double presync_us = 0.0, admit_us = 0.0;
+};
 }
 
 struct RlTraceUnit {
@@ -99,12 +111,8 @@ struct RlTraceUnit {
     bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
     uint64_t session_paths = 0, session_segments = 0; // of this unit's calls that open launches served
-    // a render that was begun and not yet ended (rl_trace_unit_render_begin / _end)
-    Session* ticket_session = nullptr; // the open launch it was appended to (null: a plain launch on `stream`, or none)
-    uint32_t ticket_job = 0;
-    uint64_t ticket_paths = 0;
-    bool ticket_unfused = false, ticket_pending = false;
-    double ticket_presync_us = 0.0, ticket_admit_us = 0.0;
+    Ticket ticket;                        // rl_trace_unit_render_begin
+    std::vector<RlPlotUnit*> fused_begun; // plot units holding a ticket of a fused render begun on this unit
 };
 
 struct RlPlotUnit {
@@ -117,6 +125,7 @@ struct RlPlotUnit {
     hipEvent_t plotted; // recorded after the last plot kernel of a PlotUnit::plot call
     hipEvent_t ready;   // recorded on `stream` when a gather (or a reader on another stream) takes the buffer
     hipEvent_t cleared; // recorded on the gather stream after accumulate + clear
+    Ticket ticket;      // rl_trace_unit_render_fused_begin: ended by whatever uses the buffer next (plot_settle)
 };
 
 struct RlGatherUnit {
@@ -385,6 +394,8 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
 namespace {
 int sessions_quiesce(int device, double* ms);
 int render_end(RlTraceUnit* u);
+int plot_settle(RlPlotUnit* plot);
+int drain_fused(RlTraceUnit* u);
 }
 
 int rl_scene_destroy(RlScene* scene) {
@@ -721,21 +732,22 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
             if (!retry) d->changed.wait_for(guard, std::chrono::microseconds(50));
         }
     }
-    u->ticket_session = mine;
-    u->ticket_job = (uint32_t)k;
-    u->ticket_paths = n_paths;
-    u->ticket_unfused = plot == nullptr;
-    u->ticket_pending = true;
-    u->ticket_presync_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
-    u->ticket_admit_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    Ticket& t = plot ? plot->ticket : u->ticket;
+    t.pending = true;
+    t.session = mine;
+    t.job = (uint32_t)k;
+    t.paths = n_paths;
+    t.owner = u;
+    t.presync_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    t.admit_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
     return RL_OK;
 }
 
 // Second half: waits until the call's paths are finished.
-int session_end(RlTraceUnit* u) {
-    Session* mine = u->ticket_session;
-    const uint32_t k = u->ticket_job;
-    DeviceSessions* d = sessions_of(u->device);
+int session_end(Ticket& t) {
+    Session* mine = t.session;
+    const uint32_t k = t.job;
+    DeviceSessions* d = sessions_of(t.owner->device);
     const auto t2 = std::chrono::steady_clock::now();
     int rc = session_wait(*mine, k);
 #ifdef RL_OPEN_DEBUG
@@ -753,17 +765,16 @@ int session_end(RlTraceUnit* u) {
         const auto t3 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> guard(d->lock);
         mine->waiters -= 1;
-        d->presync_us += u->ticket_presync_us;
-        d->admit_us += u->ticket_admit_us;
+        d->presync_us += t.presync_us;
+        d->admit_us += t.admit_us;
         d->wait_us += std::chrono::duration<double, std::micro>(t3 - t2).count();
         d->calls += 1;
     }
-    u->ticket_session = nullptr;
-    u->ticket_pending = false;
+    t.session = nullptr;
+    t.pending = false;
     if (rc != RL_OK) return rc;
-    u->session_paths += u->ticket_paths;
-    u->session_segments += job_segments;
-    if (u->ticket_unfused) RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
+    t.owner->session_paths += t.paths;
+    t.owner->session_segments += job_segments;
     return RL_OK;
 }
 
@@ -774,28 +785,72 @@ int render_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_
                  uint64_t n_paths) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    if (u->ticket_pending) return fail(RL_E_STATE, "the trace unit has a render that was begun and not ended");
+    if (!plot && u->ticket.pending) return fail(RL_E_STATE, "the trace unit has a render that was begun and not ended");
+    if (plot && (rc = plot_settle(plot)) != RL_OK) return rc; // the plot unit's previous begun render first
     if (n_paths == 0) return RL_OK;
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     if (first_path_index + n_paths < first_path_index || first_path_index + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
-    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
-    // a ragged or a huge batch: a launch of its own on the unit's stream
-    rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
+    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) {
+        rc = session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+    } else { // a ragged or a huge batch: a launch of its own on the unit's stream
+        if (plot) rc = drain_fused(u); // (the stream is about to carry another launch: earlier tickets that wait on it end first)
+        if (rc == RL_OK) rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
+        if (rc == RL_OK) {
+            Ticket& t = plot ? plot->ticket : u->ticket;
+            t.pending = true;
+            t.session = nullptr;
+            t.owner = u;
+        }
+    }
+    if (rc == RL_OK && plot) u->fused_begun.push_back(plot);
+    return rc;
+}
+
+// Ends the fused render that splats into `plot`, if one was begun: everything that reads, clears or adds to the buffer
+// calls this first.
+int plot_settle(RlPlotUnit* plot) {
+    Ticket& t = plot->ticket;
+    if (!t.pending) return RL_OK;
+    int rc = use_device(plot->device);
     if (rc != RL_OK) return rc;
-    u->ticket_session = nullptr;
-    u->ticket_pending = true;
+    RlTraceUnit* owner = t.owner;
+    for (size_t i = 0; i < owner->fused_begun.size(); ++i)
+        if (owner->fused_begun[i] == plot) {
+            owner->fused_begun.erase(owner->fused_begun.begin() + (long)i);
+            break;
+        }
+    if (t.session) return session_end(t);
+    t.pending = false;
+    RL_HIP(hipStreamSynchronize(owner->stream));
     return RL_OK;
 }
 
+int drain_fused(RlTraceUnit* u) {
+    int rc = RL_OK;
+    while (!u->fused_begun.empty()) {
+        const int rc_one = plot_settle(u->fused_begun.back()); // removes it from the list
+        if (rc == RL_OK) rc = rc_one;
+    }
+    return rc;
+}
+
+// Ends every render begun on `u`: its own (un-fused) and the fused ones whose tickets its plot units hold.
 int render_end(RlTraceUnit* u) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    if (!u->ticket_pending) return RL_OK;
-    if (u->ticket_session) return session_end(u);
-    u->ticket_pending = false;
+    rc = drain_fused(u);
+    Ticket& t = u->ticket;
+    if (!t.pending) return rc;
+    if (t.session) {
+        const int rc_own = session_end(t);
+        if (rc_own != RL_OK) return rc_own;
+        RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
+        return rc;
+    }
+    t.pending = false;
     RL_HIP(hipStreamSynchronize(u->stream));
-    return RL_OK;
+    return rc;
 }
 
 } // namespace
@@ -833,7 +888,7 @@ int rl_trace_unit_render_fused_sync(RlTraceUnit* u, const RlScene* scene, RlPlot
                                     uint64_t first_path_index, uint64_t n_paths) {
     int rc = check_fused(u, scene, plot);
     if (rc == RL_OK) rc = render_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
-    return rc != RL_OK ? rc : render_end(u);
+    return rc != RL_OK ? rc : plot_settle(plot);
 }
 
 int rl_trace_unit_render_fused_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_t seed, uint32_t stream,
@@ -864,6 +919,7 @@ int rl_trace_unit_photons(RlTraceUnit* u, RlMappedPhoton* out) {
     if (!u || !out) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = render_end(u)) != RL_OK) return rc; // a render that was begun: its photons are complete after this
     RL_HIP(hipStreamSynchronize(u->stream));
     RL_HIP(hipMemcpy(out, u->photons, (size_t)u->n_photons * sizeof(RlMappedPhoton), hipMemcpyDeviceToHost));
     return RL_OK;
@@ -871,7 +927,7 @@ int rl_trace_unit_photons(RlTraceUnit* u, RlMappedPhoton* out) {
 
 int rl_trace_unit_stats(RlTraceUnit* u, uint64_t* paths, uint64_t* segments, double* kernel_ms) {
     if (!u) return fail(RL_E_INVALID, "null trace unit");
-    int rc = use_device(u->device);
+    int rc = render_end(u); // renders that were begun are counted when they end
     if (rc != RL_OK) return rc;
     RL_HIP(hipStreamSynchronize(u->stream));
     if ((rc = drain_events(u)) != RL_OK) return rc;
@@ -929,6 +985,7 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
 int rl_plot_unit_destroy(RlPlotUnit* u) {
     if (!u) return RL_OK;
     (void)hipSetDevice(u->device);
+    (void)plot_settle(u); // a fused render that was begun splats into this buffer until it is complete
     if (u->stream) {
         (void)hipStreamSynchronize(u->stream);
         (void)hipStreamDestroy(u->stream);
@@ -946,12 +1003,14 @@ int rl_plot_unit_plot(RlPlotUnit* u, RlTraceUnit* const* trace_units, uint32_t n
     if (!u || (!trace_units && n_trace_units)) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     int cus = 256;
     if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
     const float aspect = (float)u->width / (float)u->height; // plot_unit.rs:48
     for (uint32_t k = 0; k < n_trace_units; ++k) {           // app.rs:138-140
         RlTraceUnit* t = trace_units[k];
         if (!t || t->device != u->device) return fail(RL_E_STATE, "trace unit missing or on another device");
+        if ((rc = render_end(t)) != RL_OK) return rc;          // a render that was begun: its photons are complete after this
         RL_HIP(hipStreamWaitEvent(u->stream, t->rendered, 0)); // mapped_photons complete (a no-op after a synchronous render)
         hipLaunchKernelGGL(rl_plot_kernel, dim3(grid_for(t->n_photons, cus)), dim3(RL_BLOCK), 0, u->stream, t->photons,
                            t->n_photons, u->cie, u->width, u->height, aspect, u->xyz);
@@ -970,6 +1029,7 @@ int rl_plot_unit_clear(RlPlotUnit* u) {
     if (!u) return fail(RL_E_INVALID, "null plot unit");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     RL_HIP(hipMemsetAsync(u->xyz, 0, (size_t)u->width * u->height * 3 * sizeof(float), u->stream));
     RL_HIP(hipEventRecord(u->cleared, u->stream)); // later fused renders wait for this
     return RL_OK;
@@ -979,12 +1039,15 @@ int rl_plot_unit_sync(RlPlotUnit* u) {
     if (!u) return fail(RL_E_INVALID, "null plot unit");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     RL_HIP(hipStreamSynchronize(u->stream));
     return RL_OK;
 }
 
 int rl_plot_unit_device_buffer(RlPlotUnit* u, float** device_xyz) {
     if (!u || !device_xyz) return fail(RL_E_INVALID, "null argument");
+    const int rc = plot_settle(u);
+    if (rc != RL_OK) return rc;
     *device_xyz = u->xyz;
     return RL_OK;
 }
@@ -993,6 +1056,7 @@ int rl_plot_unit_upload(RlPlotUnit* u, const RlVector3* in) {
     if (!u || !in) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     RL_HIP(hipStreamSynchronize(u->stream));
     RL_HIP(hipMemcpy(u->xyz, in, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyHostToDevice));
     RL_HIP(hipDeviceSynchronize());
@@ -1003,6 +1067,7 @@ int rl_plot_unit_download(RlPlotUnit* u, RlVector3* out) {
     if (!u || !out) return fail(RL_E_INVALID, "null argument");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     RL_HIP(hipStreamSynchronize(u->stream));
     RL_HIP(hipMemcpy(out, u->xyz, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyDeviceToHost));
     return RL_OK;
@@ -1057,6 +1122,7 @@ int rl_gather_unit_accumulate(RlGatherUnit* u, RlPlotUnit* plot) {
         return fail(RL_E_STATE, "plot unit does not match the gather unit (device or size)");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(plot)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     int cus = 256;
     if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
     const uint64_t n_floats = (uint64_t)u->width * u->height * 3;
@@ -1372,6 +1438,7 @@ int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
     if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     const size_t count = (size_t)u->width * u->height * 3;
     // In place on the root; on the plot unit's stream, i.e. after every plot / fused splat into this buffer.
     RL_NCCL(api, api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream));
@@ -1385,6 +1452,7 @@ int rl_plot_unit_add(RlPlotUnit* dst, RlPlotUnit* src) {
         return fail(RL_E_STATE, "plot units do not match (device or size)");
     int rc = use_device(dst->device);
     if (rc != RL_OK) return rc;
+    if ((rc = plot_settle(dst)) != RL_OK || (rc = plot_settle(src)) != RL_OK) return rc; // begun fused renders end first
     int cus = 256;
     if ((rc = cu_count_of(dst->device, &cus)) != RL_OK) return rc;
     const uint64_t n = (uint64_t)dst->width * dst->height * 3;

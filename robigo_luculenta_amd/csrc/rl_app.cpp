@@ -191,16 +191,16 @@ void execute_task(AppState& a, const RlTask& task) {
         break;
     case RL_TASK_TRACE: // app.rs:132-134, on every rank at once
         if (!c.fused) {
-            // Default: the blocking rl_trace_unit_render, like a reference worker -- the workers' calls share open
-            // launches on their device (measured: 11.3 Grays/s at 8 workers against 6.8 for queueing every batch as its
-            // own launch and moving on, RlAppConfig::queued_trace) -- in its two halves, so that with several ranks the
-            // call is begun on every device before any is waited for.  Ranks that share a device (a test layout) would
-            // only take turns at it with their open launches (one kernel serves one RNG stream): they get a launch per
-            // batch each instead.
-            const bool open_launches = !c.queued_trace && a.distinct_devices;
+            // A Trace task BEGINS TraceUnit::render (rl_trace_unit_render_begin: the call joins the device's open launch,
+            // rl_api.hip) and the worker moves on; the Plot task that takes the unit ends it (rl_plot_unit_plot waits for the
+            // photons it plots).  With 3 x concurrency trace units in circulation that keeps the device fed even by one or
+            // two workers (measured un-fused at 1 / 4 / 8 workers: 7.2 / 12.2 / 13.0 Grays/s, against 3.7 / 8.6 / 11.1 when
+            // the Trace task waits for its own batch like a reference worker: RlAppConfig::blocking_trace).
+            // Ranks that share a device (a test layout) would only take turns at it with their open launches (one kernel
+            // serves one RNG stream): they get a plain launch per batch each instead.
             for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
                 RlTraceUnit* u = a.ranks[r].trace_units[task.unit];
-                if (open_launches) {
+                if (a.distinct_devices) {
                     rc = rl_trace_unit_render_begin(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 } else {
                     rc = rl_trace_unit_sync(u); // back-pressure: this unit's previous launch (long finished, normally)
@@ -208,7 +208,7 @@ void execute_task(AppState& a, const RlTask& task) {
                         rc = rl_trace_unit_render_async(u, a.ranks[r].scene, c.seed, c.stream + (uint32_t)r, a.trace_first_path[task.unit]);
                 }
             }
-            if (!c.queued_trace)
+            if (c.blocking_trace)
                 for (size_t r = 0; r < a.ranks.size(); ++r) { // every begun call is ended, also after an error
                     const int rc_end = rl_trace_unit_sync(a.ranks[r].trace_units[task.unit]);
                     if (rc == RL_OK) rc = rc_end;
@@ -232,22 +232,19 @@ void execute_task(AppState& a, const RlTask& task) {
             if (task.n_units != 0) {
                 const uint64_t n = (uint64_t)task.n_units * (uint64_t)a.photons;
                 const uint64_t first = a.fused_next_path.fetch_add(n);
-                const bool open_launches = !c.queued_trace && a.distinct_devices; // as for un-fused Trace tasks above
                 for (size_t r = 0; r < a.ranks.size() && rc == RL_OK; ++r) {
                     RlTraceUnit* u = a.ranks[r].trace_units[task.units[0]];
-                    if (open_launches) { // the workers' Plot tasks share open launches on their device
+                    if (a.distinct_devices) { // begun here, ended by the Gather task that takes the plot unit (as above)
                         rc = rl_trace_unit_render_fused_begin(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
                                                               c.stream + (uint32_t)r, first, n);
                     } else {
-                        if (c.queued_trace) rc = rl_trace_unit_sync(u); // back-pressure only: this unit's previous launch
-                        if (rc == RL_OK)
-                            rc = rl_trace_unit_render_fused(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
-                                                            c.stream + (uint32_t)r, first, n);
+                        rc = rl_trace_unit_render_fused(u, a.ranks[r].scene, a.ranks[r].plot_units[task.unit], c.seed,
+                                                        c.stream + (uint32_t)r, first, n);
                     }
                 }
-                if (!c.queued_trace)
+                if (c.blocking_trace)
                     for (size_t r = 0; r < a.ranks.size(); ++r) {
-                        const int rc_end = rl_trace_unit_sync(a.ranks[r].trace_units[task.units[0]]);
+                        const int rc_end = rl_plot_unit_sync(a.ranks[r].plot_units[task.unit]);
                         if (rc == RL_OK) rc = rc_end;
                     }
             }

@@ -17,7 +17,11 @@
 //     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
 //     in fused mode the paths that ended on a light wait in a per-wave LDS queue until 64 of them can
 //     be evaluated (f64 Planck term) and splatted with a full exec mask;
-//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (~95 % busy).
+//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (one instruction per 3.0
+//     cycles per SIMD, 90 % of what a plain multiply/add stream reaches at this occupancy);
+//   * OPEN variant: the kernel stays resident and takes the paths of blocking render calls from a job table the host
+//     appends to while it runs (RlOpenDev / RlOpenCtl below); at most 120 VGPRs so that the small kernels of the other
+//     units run beside it.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -560,8 +564,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     bool drained = false;                       // wave-uniform: the queue has no more paths for this wave
     bool active = false;
     uint64_t my_path = 0;  // the path's index in its RNG stream
-    uint32_t my_job = 0;   // merged launches: which job the path belongs to
-    uint32_t stash_job = 0;               // wave-uniform: the job of the stash's current content
+    uint32_t my_job = 0;   // open launches: which job the path belongs to
+    uint32_t stash_job = 0;               // wave-uniform, open launches: the job of the stash's current content
     uint64_t stash_first = job.first_path; // wave-uniform: path index of launch offset 0 as seen by that job
     RlPath p;
     p.origin = rl_f3(0.0f, 0.0f, 0.0f); // a lane without a path scans a null ray; rl_scan_wave's idle_bit mutes it

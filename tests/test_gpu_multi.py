@@ -403,17 +403,27 @@ def test_render_in_two_halves_begin_on_many_units_then_end(R):
     for i, u in enumerate(units):
         u.render_begin(scene, seed=4, stream=3, first_path_index=1000 * i)
     fused.render_fused_begin(scene, plot, 3 * n, seed=4, stream=3, first_path_index=77)
+    plot2 = R.PlotUnit(1, W, H)
+    fused.render_fused_begin(scene, plot2, n, seed=4, stream=3, first_path_index=9000)   # the ticket is the plot unit's: the trace unit is free
     with pytest.raises(R.RlError):
         units[0].render_begin(scene, seed=4, stream=3, first_path_index=0)       # one begun render per unit
     for u in reversed(units):
         u.render_end()
     units[2].render_end()                                                       # nothing begun: a no-op
-    fused.sync()                                                                # sync ends a begun render too
+    g = R.GatherUnit(W, H)
+    plot3 = R.PlotUnit(2, W, H)
+    fused.render_fused_begin(scene, plot3, n, seed=4, stream=3, first_path_index=9000)
+    g.accumulate(plot3)                                                         # a consumer of the buffer ends the begun render
+    assert np.allclose(g.tristimulus_buffer, plot2.tristimulus_buffer, rtol=2e-5, atol=1e-7)
+    fused.sync()                                                                # the trace unit's sync ends what it began
     for i, u in enumerate(units):
         want, segs = oscene.render(W, H, 4, 3, 1000 * i, n, threads=2)
         assert u.mapped_photons.tobytes() == want.tobytes() and u.stats()[:2] == (n, segs)
     photons, segs = oscene.render(W, H, 4, 3, 77, 3 * n, threads=2)
-    assert np.allclose(plot.tristimulus_buffer, O.plot(W, H, photons), rtol=2e-5, atol=1e-7) and fused.stats()[:2] == (3 * n, segs)
+    photons2, segs2 = oscene.render(W, H, 4, 3, 9000, n, threads=2)
+    assert np.allclose(plot2.tristimulus_buffer, O.plot(W, H, photons2), rtol=2e-5, atol=1e-7)   # the download ends the begun render
+    assert np.allclose(plot.tristimulus_buffer, O.plot(W, H, photons), rtol=2e-5, atol=1e-7)
+    assert fused.stats()[:2] == (5 * n, segs + 2 * segs2)                       # plot, plot2 and plot3 (the same range as plot2)
     ragged = R.TraceUnit(10, W, H, n_photons=1000)                               # not a multiple of 64: a launch of its own
     ragged.render_begin(scene, seed=4, stream=3, first_path_index=5)
     ragged.render_end()

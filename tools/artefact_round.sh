@@ -18,14 +18,15 @@ for s in demo glass replicated; do timeout 120 python tools/kernel_stats.py 64 $
 python - > $OUT/app.txt <<'PY'
 import robigo_luculenta_amd as R
 print("rl_app_run, built-in scene, 1280x720, 4096 batches of 524288 paths (trace_unit.rs:67), seconds include the final tonemap")
-for fused in (False, True):
-    for c in (1, 4, 8, 16):
-        rgb, st = R.app_run(1280, 720, 4096, concurrency=c, photons_per_batch=524288, fused=fused, verbose=False)
-        print("fused" if fused else "un-fused", "workers", c, round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6),
-              "Mrays/s", round(st["paths"] / 524288 / st["seconds"]), "batches/s", st["tasks"], flush=True)
+for blocking in (False, True):
+    print("tasks begin their render, the next task that uses it ends it (default):" if not blocking else
+          "tasks wait for their own paths like a reference worker (blocking_trace):")
+    for fused in (False, True):
+        for c in (1, 2, 4, 8, 16):
+            rgb, st = R.app_run(1280, 720, 4096, concurrency=c, photons_per_batch=524288, fused=fused, blocking_trace=blocking, verbose=False)
+            print(" ", "fused" if fused else "un-fused", "workers", c, round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6),
+                  "Mrays/s", round(st["paths"] / 524288 / st["seconds"]), "batches/s", st["tasks"], flush=True)
 print("open launches so far, {calls carried: launches}:", R.batch_histogram())
-rgb, st = R.app_run(1280, 720, 4096, concurrency=8, photons_per_batch=524288, fused=False, queued_trace=True, verbose=False)
-print("un-fused workers 8, queued trace tasks (one launch per batch, nobody waits)", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
 for fused in (False, True):
     rgb, st = R.app_run(1280, 720, 96, concurrency=2, photons_per_batch=64 * 524288, fused=fused, verbose=False)
     print("fused" if fused else "un-fused", "64-batch tasks, workers 2", round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
