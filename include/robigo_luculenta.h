@@ -187,10 +187,11 @@ int rl_trace_unit_render_fused(RlTraceUnit* unit, const RlScene* scene, RlPlotUn
  * the order of the float atomics. */
 int rl_trace_unit_render_fused_sync(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                     uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
-/* Its first half.  The begun render belongs to `plot` (the trace unit is free for the next call at once) and is ended
- * by whatever uses the plot unit's buffer next: rl_gather_unit_accumulate / _allreduce, rl_plot_unit_reduce / _add /
- * _plot / _clear / _sync / _download / _upload / _device_buffer / _destroy, another render begun into it -- or by
- * rl_trace_unit_render_end / _sync / _destroy of the trace unit it was begun on. */
+/* Its first half.  The begun render belongs to `plot` -- the trace unit is free for the next call, on any thread, at
+ * once and may even be destroyed -- and is ended by whatever uses the plot unit's buffer next: rl_plot_unit_sync,
+ * rl_gather_unit_accumulate / _allreduce, rl_plot_unit_reduce / _add / _plot / _clear / _download / _upload /
+ * _device_buffer / _destroy, or another render begun into it.  Its paths and segments appear in the trace unit's
+ * rl_trace_unit_stats once it has ended. */
 int rl_trace_unit_render_fused_begin(RlTraceUnit* unit, const RlScene* scene, RlPlotUnit* plot, uint64_t seed,
                                      uint32_t stream, uint64_t first_path_index, uint64_t n_paths);
 int rl_trace_unit_sync(RlTraceUnit* unit);

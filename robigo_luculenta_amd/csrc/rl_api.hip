@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -82,15 +84,23 @@ struct RlScene {
 namespace {
 struct Session;
 
+// Paths and segments of a trace unit's calls that open launches served.  Shared with the tickets of the fused renders
+// begun on the unit, which are ended on other threads (whoever uses the plot unit next) and possibly after the unit is gone.
+struct UnitCounters {
+    std::atomic<uint64_t> paths{0}, segments{0};
+};
+
 // A blocking render that was begun and not yet ended.  The ticket of an un-fused render lives in its trace unit (whose
 // photons it fills), that of a fused render in the PLOT unit it splats into: the trace unit only lends its image size
-// and fetch mode, and is free for the next call at once.
+// and fetch mode and is free for the next call -- on whatever thread -- at once, so the ticket holds nothing of it but
+// the counters to credit.
 struct Ticket {
     bool pending = false;
-    Session* session = nullptr; // the open launch the call was appended to; null: a plain launch on owner->stream
+    Session* session = nullptr; // the open launch the call was appended to; null: a plain launch (ragged or huge batch)
     uint32_t job = 0;
     uint64_t paths = 0;
-    RlTraceUnit* owner = nullptr; // the trace unit the call was made on (its counters are credited)
+    int device = 0;
+    std::shared_ptr<UnitCounters> counters;
     double presync_us = 0.0, admit_us = 0.0;
 };
 }
@@ -110,9 +120,8 @@ struct RlTraceUnit {
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
     bool tuned_stage, tuned_fused; // kernel variant,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
-    uint64_t session_paths = 0, session_segments = 0; // of this unit's calls that open launches served
-    Ticket ticket;                        // rl_trace_unit_render_begin
-    std::vector<RlPlotUnit*> fused_begun; // plot units holding a ticket of a fused render begun on this unit
+    std::shared_ptr<UnitCounters> counters = std::make_shared<UnitCounters>(); // of this unit's calls that open launches served
+    Ticket ticket;                                                               // rl_trace_unit_render_begin
 };
 
 struct RlPlotUnit {
@@ -395,7 +404,6 @@ namespace {
 int sessions_quiesce(int device, double* ms);
 int render_end(RlTraceUnit* u);
 int plot_settle(RlPlotUnit* plot);
-int drain_fused(RlTraceUnit* u);
 }
 
 int rl_scene_destroy(RlScene* scene) {
@@ -737,7 +745,8 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
     t.session = mine;
     t.job = (uint32_t)k;
     t.paths = n_paths;
-    t.owner = u;
+    t.device = u->device;
+    t.counters = u->counters;
     t.presync_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
     t.admit_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
     return RL_OK;
@@ -747,7 +756,7 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
 int session_end(Ticket& t) {
     Session* mine = t.session;
     const uint32_t k = t.job;
-    DeviceSessions* d = sessions_of(t.owner->device);
+    DeviceSessions* d = sessions_of(t.device);
     const auto t2 = std::chrono::steady_clock::now();
     int rc = session_wait(*mine, k);
 #ifdef RL_OPEN_DEBUG
@@ -772,10 +781,12 @@ int session_end(Ticket& t) {
     }
     t.session = nullptr;
     t.pending = false;
-    if (rc != RL_OK) return rc;
-    t.owner->session_paths += t.paths;
-    t.owner->session_segments += job_segments;
-    return RL_OK;
+    if (rc == RL_OK) {
+        t.counters->paths += t.paths;
+        t.counters->segments += job_segments;
+    }
+    t.counters.reset();
+    return rc;
 }
 
 #define RL_SESSION_MAX_PATHS (1ull << 28) // per call: its segment count must fit 32 bits
@@ -791,20 +802,15 @@ int render_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     if (first_path_index + n_paths < first_path_index || first_path_index + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
-    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) {
-        rc = session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
-    } else { // a ragged or a huge batch: a launch of its own on the unit's stream
-        if (plot) rc = drain_fused(u); // (the stream is about to carry another launch: earlier tickets that wait on it end first)
-        if (rc == RL_OK) rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
-        if (rc == RL_OK) {
-            Ticket& t = plot ? plot->ticket : u->ticket;
-            t.pending = true;
-            t.session = nullptr;
-            t.owner = u;
-        }
-    }
-    if (rc == RL_OK && plot) u->fused_begun.push_back(plot);
-    return rc;
+    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+    // a ragged or a huge batch: a launch of its own on the unit's stream (a fused one is waited for by the plot unit's stream)
+    rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
+    if (rc != RL_OK) return rc;
+    Ticket& t = plot ? plot->ticket : u->ticket;
+    t.pending = true;
+    t.session = nullptr;
+    t.device = u->device;
+    return RL_OK;
 }
 
 // Ends the fused render that splats into `plot`, if one was begun: everything that reads, clears or adds to the buffer
@@ -814,43 +820,26 @@ int plot_settle(RlPlotUnit* plot) {
     if (!t.pending) return RL_OK;
     int rc = use_device(plot->device);
     if (rc != RL_OK) return rc;
-    RlTraceUnit* owner = t.owner;
-    for (size_t i = 0; i < owner->fused_begun.size(); ++i)
-        if (owner->fused_begun[i] == plot) {
-            owner->fused_begun.erase(owner->fused_begun.begin() + (long)i);
-            break;
-        }
     if (t.session) return session_end(t);
     t.pending = false;
-    RL_HIP(hipStreamSynchronize(owner->stream));
+    RL_HIP(hipStreamSynchronize(plot->stream)); // it waits for the launch (launch_trace)
     return RL_OK;
 }
 
-int drain_fused(RlTraceUnit* u) {
-    int rc = RL_OK;
-    while (!u->fused_begun.empty()) {
-        const int rc_one = plot_settle(u->fused_begun.back()); // removes it from the list
-        if (rc == RL_OK) rc = rc_one;
-    }
-    return rc;
-}
-
-// Ends every render begun on `u`: its own (un-fused) and the fused ones whose tickets its plot units hold.
+// Ends the un-fused render begun on `u`, if any.
 int render_end(RlTraceUnit* u) {
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    rc = drain_fused(u);
     Ticket& t = u->ticket;
-    if (!t.pending) return rc;
+    if (!t.pending) return RL_OK;
     if (t.session) {
-        const int rc_own = session_end(t);
-        if (rc_own != RL_OK) return rc_own;
+        if ((rc = session_end(t)) != RL_OK) return rc;
         RL_HIP(hipEventRecord(u->rendered, u->stream)); // PlotUnit::plot waits for this (complete already)
-        return rc;
+        return RL_OK;
     }
     t.pending = false;
     RL_HIP(hipStreamSynchronize(u->stream));
-    return rc;
+    return RL_OK;
 }
 
 } // namespace
@@ -936,8 +925,8 @@ int rl_trace_unit_stats(RlTraceUnit* u, uint64_t* paths, uint64_t* segments, dou
     // Calls served by open launches are counted per call (session_*); the kernel time of those launches, which serve
     // many units at once, is credited to whichever unit asks first.
     if ((rc = sessions_quiesce(u->device, &u->kernel_ms)) != RL_OK) return rc;
-    if (segments) *segments = q[1] + u->session_segments;
-    if (paths) *paths = q[2] + u->session_paths;
+    if (segments) *segments = q[1] + u->counters->segments.load();
+    if (paths) *paths = q[2] + u->counters->paths.load();
     if (kernel_ms) *kernel_ms = u->kernel_ms;
     return RL_OK;
 }

@@ -468,3 +468,17 @@ def test_results_of_a_call_are_visible_the_moment_it_returns(R, fused):
         photons, _ = oscene.render(W, H, 13, 0, (rnd * workers + i) * n, n, threads=2)
         want = O.plot(W, H, photons)
         assert np.allclose(xyz, want, rtol=2e-5, atol=1e-7), (i, rnd, float(np.abs(xyz - want).max()))
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("blocking", [False, True])
+def test_app_with_many_workers_traces_every_path_exactly_once(R, fused, blocking):
+    """16 workers over 48 trace units and 8 plot units: renders are begun on one thread and ended on another (whoever
+    plots / gathers next), trace units change hands while fused renders begun on them are still in flight.  Whatever
+    the interleaving, the paths [0, batches * n) are traced exactly once: the segment total is the oracle's."""
+    W, H, n, batches = 64, 36, 1 << 10, 600
+    rgb, st = R.app_run(W, H, batches, concurrency=16, photons_per_batch=n, seed=9, fused=fused, blocking_trace=blocking)
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    _, segs = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam)).render(W, H, 9, 0, 0, batches * n, threads=8)
+    assert st["batches"] == batches and st["paths"] == batches * n and st["segments"] == segs
+    assert rgb.any()
