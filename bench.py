@@ -197,7 +197,7 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
                                      "frac": achieved / PEAK_FP32_VECTOR_TFLOPS}}
 
 
-def measure_app(R, fused, workers, device, batches=2048):
+def measure_app(R, fused, workers, device, batches=8192):
     """The drop-in at the reference's own task size: rl_app_run (TaskScheduler + worker pool, csrc/rl_app.cpp) with Trace
     tasks of 524,288 paths (trace_unit.rs:67) and as many workers as the host has cores (app.rs:55), at 1280x720."""
     rgb, st = R.app_run(1280, 720, batches, concurrency=workers, photons_per_batch=BATCH, fused=fused, verbose=False, device=device)
