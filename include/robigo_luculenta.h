@@ -165,7 +165,9 @@ int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed,
  * taking the next task: rl_app_run does both): _begin appends the call to the device's open launch (or starts one) and
  * returns at once, _end waits until the call's paths are finished (a no-op without a begun render).  One begun render
  * per unit at a time.  Everything that reads mapped_photons ends a begun render by itself: rl_plot_unit_plot (for the
- * units it plots), rl_trace_unit_photons, rl_trace_unit_sync, rl_trace_unit_stats, rl_trace_unit_destroy. */
+ * units it plots), rl_trace_unit_photons, rl_trace_unit_sync, rl_trace_unit_stats, rl_trace_unit_destroy.  The thread
+ * that ends a render need not be the one that began it, as long as the unit changes hands the way every unit must
+ * (one user at a time, handed over through a lock or a channel -- the reference's Task does that). */
 int rl_trace_unit_render_begin(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                                uint64_t first_path_index);
 int rl_trace_unit_render_end(RlTraceUnit* unit);

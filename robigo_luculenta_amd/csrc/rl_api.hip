@@ -759,16 +759,6 @@ int session_end(Ticket& t) {
     DeviceSessions* d = sessions_of(t.device);
     const auto t2 = std::chrono::steady_clock::now();
     int rc = session_wait(*mine, k);
-#ifdef RL_OPEN_DEBUG
-    {
-        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t2).count();
-        const RlOpenCtl* c = mine->ctl;
-        if (k >= 100 && k < 140)
-            fprintf(stderr, "job %u: host wait %.0f us | gpu (us since job 100 known): known %.1f first %.1f last %.1f done %.1f\n", k, host_us,
-                    (double)(long long)(c->t_known[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_first[k] - c->t_known[100]) / 100.0,
-                    (double)(long long)(c->t_last[k] - c->t_known[100]) / 100.0, (double)(long long)(c->t_done[k] - c->t_known[100]) / 100.0);
-    }
-#endif
     const uint64_t job_segments = host_load(&mine->ctl->segs[k]);
     {
         const auto t3 = std::chrono::steady_clock::now();

@@ -98,9 +98,6 @@ struct RlOpenCtl {
     uint32_t done[RL_OPEN_CAP];
     uint32_t segs[RL_OPEN_CAP]; // valid once done[j] is set
     RlJobEntry jobs[RL_OPEN_CAP];
-#ifdef RL_OPEN_DEBUG
-    unsigned long long t_known[RL_OPEN_CAP], t_first[RL_OPEN_CAP], t_last[RL_OPEN_CAP], t_done[RL_OPEN_CAP];
-#endif
 };
 
 // Diagnostic build only (make stats): wave-level event counters of the trace kernel, read back by
@@ -635,9 +632,6 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                     __hip_atomic_fetch_add(&od->completed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t total = __hip_atomic_load(&od->seg[jb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ctl->segs[jb], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#ifdef RL_OPEN_DEBUG
-                    ctl->t_done[jb] = wall_clock64();
-#endif
                     __hip_atomic_store(&ctl->done[jb], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
@@ -719,10 +713,6 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                             b = __builtin_amdgcn_readfirstlane(b);
                             if (b < open_n) {
                                 chunk_end = b + take < open_n ? b + take : ((open_n + 63u) & ~63u);
-#ifdef RL_OPEN_DEBUG
-                                if (lane == 0 && b == 0) ctl->t_first[stash_job] = wall_clock64();
-                                if (lane == 0 && b + take >= open_n) ctl->t_last[stash_job] = wall_clock64();
-#endif
                                 chunk_next = b;
                                 got = true;
                                 break;
@@ -770,9 +760,6 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                         if (pub > RL_OPEN_CAP) pub = RL_OPEN_CAP;
                         if (pub > known_local) { // new calls: copy their entries to device memory, then make them known
                             for (uint32_t k = known_local + lane; k < pub; k += 64u) {
-#ifdef RL_OPEN_DEBUG
-                                ctl->t_known[k] = wall_clock64();
-#endif
                                 unsigned long long* dst = (unsigned long long*)&od->jobs[k];
                                 const unsigned long long* src = (const unsigned long long*)&ctl->jobs[k];
                                 for (int w = 0; w < 4; ++w)
