@@ -263,23 +263,34 @@ def main():
 
     if R.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    device = local_rank % R.device_count() if args.dist_backend == "gloo" else local_rank
     D.init_control_plane(rank, world)
     comm, exchange_note = None, None
     if world > 1 and args.dist_backend == "rccl":
         # The library's RCCL communicator.  Should it fail to come up on ANY rank (a box without usable xGMI / IPC),
         # every rank falls back to the host-staged exchange together and the line says so -- a measured line with
-        # a slower exchange is worth more than no line.
-        try:
-            comm = D.make_comm(R, rank, world, device)
-            failed = 0.0
-        except Exception as e:  # noqa: BLE001
-            exchange_note, failed = "rl_comm_init_rank failed on rank %d: %s" % (rank, e), 1.0
+        # a slower exchange is worth more than no line.  ncclCommInitRank is a collective: a rank that cannot even
+        # get there (no GPU of its own, RCCL not loadable) would leave the others waiting inside it for ever, so the
+        # ranks first agree that all of them can.
+        failed = 0.0
+        if local_rank >= R.device_count():
+            exchange_note, failed = "rank %d has no GPU of its own (%d visible): RCCL admits one rank per device" % (rank, R.device_count()), 1.0
+        else:
+            try:
+                R.Comm.unique_id()   # loads RCCL; the id itself is not used
+            except Exception as e:  # noqa: BLE001
+                exchange_note, failed = "RCCL is not usable on rank %d: %s" % (rank, e), 1.0
         _, (n_failed,) = D.aggregate(0.0, [failed])
+        if not n_failed:
+            try:
+                comm = D.make_comm(R, rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001
+                exchange_note, failed = "rl_comm_init_rank failed on rank %d: %s" % (rank, e), 1.0
+            _, (n_failed,) = D.aggregate(0.0, [failed])
         if n_failed:
             comm = None
-            exchange_note = exchange_note or "rl_comm_init_rank failed on another rank"
+            exchange_note = exchange_note or "the communicator did not come up on another rank"
             args.dist_backend = "gloo (fallback: %s)" % exchange_note
+    device = local_rank if comm is not None or world == 1 else local_rank % R.device_count()
 
     objs, cam, W, H, label = scene_of(R, args.config)
     scene = R.Scene(objs, cam, device=device)

@@ -218,6 +218,21 @@ def test_bench_runs_its_own_two_ranks_on_one_gpu():
     assert line["value"] > 0 and "cpu_baseline" not in line
 
 
+def test_bench_with_more_ranks_than_gpus_falls_back_instead_of_hanging(R):
+    """The default exchange is RCCL, one rank per GPU.  On a box with fewer GPUs than ranks a rank has no device of its own
+    and never reaches ncclCommInitRank -- a collective the others would wait in for ever; the ranks must agree on the
+    host-staged exchange BEFORE anybody enters it, and the line must say so."""
+    if R.device_count() >= 2:
+        pytest.skip("needs fewer GPUs than ranks")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--launches-per-step", "1", "--batches-per-launch", "4", "--config", "demo-720p"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run(cmd, env=env, capture_output=True, timeout=240, check=True).stdout.decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["dist_backend"].startswith("gloo (fallback")
+    assert line["value"] > 0
+
+
 def test_concurrent_renders_share_open_launches_and_stay_bit_exact(R):
     """The reference runs one TraceUnit::render per worker thread (app.rs:92-134).  The library appends such calls to
     a trace kernel that is already running (open launches, rl_api.hip); every unit must still receive exactly its own
