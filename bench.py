@@ -223,9 +223,21 @@ def spawn_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    # A rank that dies leaves the others waiting at the next barrier: watch all of them, stop the rest when one fails.
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=5)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
     if any(rcs):
         raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
