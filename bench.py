@@ -286,11 +286,11 @@ def main():
         failed = 0.0
         if local_rank >= R.device_count():
             exchange_note, failed = "rank %d has no GPU of its own (%d visible): RCCL admits one rank per device" % (rank, R.device_count()), 1.0
-        else:
+        elif rank == 0:   # (the other ranks load the same library on the same node)
             try:
                 R.Comm.unique_id()   # loads RCCL; the id itself is not used
             except Exception as e:  # noqa: BLE001
-                exchange_note, failed = "RCCL is not usable on rank %d: %s" % (rank, e), 1.0
+                exchange_note, failed = "RCCL is not usable: %s" % e, 1.0
         _, (n_failed,) = D.aggregate(0.0, [failed])
         if not n_failed:
             try:
