@@ -11,6 +11,9 @@
 //   * GatherUnit::accumulate runs on the gather stream after the plot stream's tail, and the plot stream
 //     continues after the clear; tonemap kernels run on the gather stream;
 //   * the GatherUnit-time exchange (rl_plot_unit_reduce, RCCL) is enqueued on the plot stream.
+//   * the blocking render calls (open launches, see `Session` below) are ordered on the HOST instead: before a call
+//     is appended to a kernel that is already running, the host waits for whatever still reads or clears its target,
+//     and the call (or whoever ends a begun one) returns only when the kernel has reported its last path.
 // Downloads synchronise the stream that produced the data.  Trace and plot work of different units overlap on
 // the device.  Entry points never throw.
 #include <hip/hip_runtime.h>
@@ -504,9 +507,11 @@ namespace {
 // on the device whenever there is one that still accepts work (same scene, seed, stream, image size, fetch mode,
 // fused or not); otherwise the call starts such a kernel with itself as the first job.  Each call returns as soon as
 // ITS paths are finished -- the kernel goes on with the other callers' -- so the drain tail of one 524,288-path batch
-// overlaps the next batches instead of idling the chip, and nothing is launched per call.  A kernel closes itself the
-// moment a wave finds nothing left to hand out; a call that arrives too late for it starts the next one, whose
-// workgroups move onto the CUs as the closed one's drain.
+// overlaps the next batches instead of idling the chip, and nothing is launched per call.  A kernel stays open while
+// calls are still finishing their last paths (their callers come back with more) and for a grace period after the
+// last one, then closes itself; a call that arrives too late for it starts the next one, whose workgroups move onto
+// the CUs as the closed one's drain.  The calls also exist in two halves (begin / end, `Ticket`): whoever uses a
+// begun render's result next ends it.
 
 struct Session {
     hipStream_t stream = nullptr;
