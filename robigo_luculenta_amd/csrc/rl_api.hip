@@ -1226,7 +1226,7 @@ int rl_tonemap_unit_tonemap(RlTonemapUnit* u, RlGatherUnit* gather) {
     int cus = 256;
     if ((rc = cu_count_of(u->device, &cus)) != RL_OK) return rc;
     const uint32_t n_pixels = u->width * u->height;
-    hipLaunchKernelGGL(rl_exposure_kernel, dim3(1), dim3(64), 0, gather->stream, gather->acc, n_pixels, (float)n_pixels,
+    hipLaunchKernelGGL(rl_exposure_kernel, dim3(1), dim3(RL_EXPOSURE_BLOCK), 0, gather->stream, gather->acc, n_pixels, (float)n_pixels,
                        u->max_intensity);
     RL_HIP(hipGetLastError());
     hipLaunchKernelGGL(rl_tonemap_kernel, dim3(grid_for(n_pixels, cus)), dim3(RL_BLOCK), 0, gather->stream, gather->acc, n_pixels,

@@ -1070,46 +1070,92 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_gather_kernel(float* __restrict__
 
 // TonemapUnit::find_exposure (tonemap_unit.rs:55-69).  The reference sums Y and Y^2 sequentially in
 // f32 over all pixels; a tree reduction would move max_intensity at the 1e-4 level and with it every
-// output pixel, so the two sums keep the reference's order: one wave, lane 0 accumulates sum(Y) and lane 1
-// sum(Y*Y) in pixel order.  Everything that is not the dependent chain is done by the whole wave first: all 64
-// lanes stream a tile of Y into LDS with coalesced loads and square it there (y * y rounds exactly as in the
-// reference's `sq + y * y`, contraction is off), so that the serial phase is one 16-byte LDS read per four
-// pixels and one dependent add per pixel (22.9 ms -> 13.7 ms at 1080p).  Runs once per tonemap (every 30 s in the
-// reference).
-#define RL_EXPOSURE_TILE 4096
-__global__ __launch_bounds__(64) void rl_exposure_kernel(const float* __restrict__ xyz, uint32_t n_pixels, float n_as_float,
-                                                         float* __restrict__ out_max) {
-    __shared__ __attribute__((aligned(16))) float tile[2][RL_EXPOSURE_TILE]; // [0] = Y, [1] = Y * Y
-    const uint32_t lane = threadIdx.x;
-    const uint32_t chain = lane < 2 ? lane : 0; // lanes 2.. only help with the loads
-    float total = 0.0f;
-    for (uint32_t start = 0; start < n_pixels; start += RL_EXPOSURE_TILE) {
+// output pixel, so the two sums keep the reference's order: lane 0 of wave 0 accumulates sum(Y) and lane 1
+// sum(Y*Y) in pixel order.  Everything that is not the dependent chain is done by the other three waves of the
+// workgroup, one tile ahead: they stream the next tile of Y into LDS and square it there (y * y rounds exactly as in
+// the reference's `sq + y * y`, contraction is off) while the chains run over the current one, so that the serial
+// phase is 16-byte LDS reads issued four ahead of their use and one dependent add per pixel.  Runs once per tonemap
+// (every 30 s in the reference).
+#define RL_EXPOSURE_TILE 2048
+#define RL_EXPOSURE_BLOCK 256
+__global__ __launch_bounds__(RL_EXPOSURE_BLOCK) void rl_exposure_kernel(const float* __restrict__ xyz, uint32_t n_pixels,
+                                                                        float n_as_float, float* __restrict__ out_max) {
+    __shared__ __attribute__((aligned(16))) float tile[2][2][RL_EXPOSURE_TILE]; // [buffer][0 = Y, 1 = Y * Y][pixel of the tile]
+    const uint32_t t = threadIdx.x;
+    const uint32_t n_tiles = (n_pixels + RL_EXPOSURE_TILE - 1) / RL_EXPOSURE_TILE;
+    auto fill = [&](uint32_t k) { // waves 1..3: tile k into buffer k & 1
+        const uint32_t start = k * RL_EXPOSURE_TILE;
         const uint32_t count = min((uint32_t)RL_EXPOSURE_TILE, n_pixels - start);
-        for (uint32_t i = lane; i < count; i += 64) {
+        float* y_out = tile[k & 1u][0];
+        float* yy_out = tile[k & 1u][1];
+#pragma unroll 8
+        for (uint32_t i = t - 64u; i < count; i += RL_EXPOSURE_BLOCK - 64u) {
             const float y = xyz[3ull * (start + i) + 1];
-            tile[0][i] = y;
-            tile[1][i] = y * y;
+            y_out[i] = y;
+            yy_out[i] = y * y;
         }
-        __syncthreads();
-        if (lane < 2) {
-            const float* mine = tile[chain];
-            const uint32_t whole = count & ~3u;
-            for (uint32_t i = 0; i < whole; i += 4) {
-                const float4 v = *(const float4*)(mine + i);
-                total = total + v.x;
-                total = total + v.y;
-                total = total + v.z;
-                total = total + v.w;
+    };
+    if (t >= 64u && n_tiles != 0) fill(0);
+    __syncthreads();
+    float total = 0.0f;
+    for (uint32_t k = 0; k < n_tiles; ++k) {
+        if (t >= 64u) {
+            if (k + 1 < n_tiles) fill(k + 1);
+        } else if (t < 2u) {
+            const uint32_t count = min((uint32_t)RL_EXPOSURE_TILE, n_pixels - k * RL_EXPOSURE_TILE);
+            const float* mine = tile[k & 1u][t];
+            // Four 16-byte LDS reads stay in flight ahead of the 16 dependent adds that consume the previous four.  The
+            // reads are inline assembly because the build's register-minimising scheduler otherwise sinks every read to
+            // just before its use (one LDS round trip per four pixels: 22 ms at 1080p instead of 10); the s_waitcnt
+            // statements take `total` as an operand so that the adds cannot move across them.
+            typedef float RlV4 __attribute__((ext_vector_type(4)));
+            uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)mine;
+            const uint32_t n16 = count / 16u;
+            RlV4 a0, a1, a2, a3, b0, b1, b2, b3; // two register sets used in turn: nothing is ever copied while a read is in flight
+#define RL_EXP_READ(R0, R1, R2, R3)                                                                                         \
+    asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:16\n\tds_read_b128 %2, %5 offset:32\n\tds_read_b128 %3, %5 offset:48" \
+                 : "=&v"(R0), "=&v"(R1), "=&v"(R2), "=&v"(R3), "+v"(total) : "v"(addr) : "memory");                          \
+    addr += 64u;
+#define RL_EXP_WAIT(R0, R1, R2, R3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3), "+v"(total));
+#define RL_EXP_ADD(R0, R1, R2, R3)                                                                      \
+    total = total + R0.x; total = total + R0.y; total = total + R0.z; total = total + R0.w;             \
+    total = total + R1.x; total = total + R1.y; total = total + R1.z; total = total + R1.w;             \
+    total = total + R2.x; total = total + R2.y; total = total + R2.z; total = total + R2.w;             \
+    total = total + R3.x; total = total + R3.y; total = total + R3.z; total = total + R3.w;
+            if (n16 != 0) {
+                RL_EXP_READ(a0, a1, a2, a3)
+                uint32_t q = 1;
+                for (; q + 1u < n16; q += 2u) {
+                    RL_EXP_WAIT(a0, a1, a2, a3)
+                    RL_EXP_READ(b0, b1, b2, b3)
+                    RL_EXP_ADD(a0, a1, a2, a3)
+                    RL_EXP_WAIT(b0, b1, b2, b3)
+                    RL_EXP_READ(a0, a1, a2, a3)
+                    RL_EXP_ADD(b0, b1, b2, b3)
+                }
+                RL_EXP_WAIT(a0, a1, a2, a3)
+                if (q < n16) {
+                    RL_EXP_READ(b0, b1, b2, b3)
+                    RL_EXP_ADD(a0, a1, a2, a3)
+                    RL_EXP_WAIT(b0, b1, b2, b3)
+                    RL_EXP_ADD(b0, b1, b2, b3)
+                } else {
+                    RL_EXP_ADD(a0, a1, a2, a3)
+                }
             }
-            for (uint32_t i = whole; i < count; ++i) total = total + mine[i];
+#undef RL_EXP_READ
+#undef RL_EXP_WAIT
+#undef RL_EXP_ADD
+            for (uint32_t i = 16u * n16; i < count; ++i) total = total + mine[i];
         }
         __syncthreads();
     }
-    const float sum_y = __shfl(total, 0);
-    const float sum_yy = __shfl(total, 1);
-    if (lane == 0) {
-        const float mean = sum_y / n_as_float;
-        const float sqr_mean = sum_yy / n_as_float;
+    __shared__ float sums[2];
+    if (t < 2u) sums[t] = total;
+    __syncthreads();
+    if (t == 0) {
+        const float mean = sums[0] / n_as_float;
+        const float sqr_mean = sums[1] / n_as_float;
         const float variance = sqr_mean - mean * mean;
         out_max[0] = mean + sqrtf(variance);
     }

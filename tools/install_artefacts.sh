@@ -5,6 +5,7 @@ TAG=$1
 SRC=gpurun_out/$TAG
 cp $SRC/trace/t_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
 cp $SRC/trace_app/t_kernel_stats.csv profiles/${TAG}_app_kernel_stats.csv
+cp $SRC/app_overlap.txt profiles/${TAG}_app_overlap.txt
 cp $SRC/bench.json profiles/${TAG}_bench.json
 cp $SRC/${TAG}_pmc.json profiles/${TAG}_pmc.json
 cp $SRC/${TAG}_pmc_summary.txt profiles/${TAG}_pmc_summary.txt

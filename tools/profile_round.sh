@@ -21,6 +21,7 @@ cp $OUT/${TAG}_pmc.json profiles/ 2>/dev/null   # so that the bench line below q
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace_app -o t -- python -c "
 import robigo_luculenta_amd as R
 R.app_run(1920, 1080, 48, concurrency=4, fused=False, tonemap_interval_ms=50)" > $OUT/trace_app.log 2>&1
+python tools/overlap_summary.py $OUT/trace_app/t_kernel_trace.csv > $OUT/app_overlap.txt 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json
 head -8 $OUT/trace/t_kernel_stats.csv
