@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """A longer rl_app_run at the reference task size (16 workers, tonemap every 5 s): 300,000 batches un-fused, 200,000 fused.
 Checks that every path is traced, prints the sustained rate and the process RSS after each run (no growth between runs)."""
-import robigo_luculenta_amd as R, os, time
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import robigo_luculenta_amd as R  # noqa: E402
+
+
 def rss():
     return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e6
 print("rss before %.0f MB" % rss())
