@@ -560,7 +560,10 @@ int sessions_setup(DeviceSessions* d) { // under d->lock, device current
     for (Session& x : d->s) {
         // a priority of its own = a hardware queue of its own: the streams of the plot / gather / tonemap kernels must
         // never queue up behind a resident trace kernel (they run beside it in the registers it leaves free)
-        RL_HIP(hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, least));
+        if (hipStreamCreateWithPriority(&x.stream, hipStreamNonBlocking, least) != hipSuccess) { // (no priorities here: a plain stream)
+            (void)hipGetLastError();
+            RL_HIP(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+        }
         RL_HIP(hipMalloc((void**)&x.od, sizeof(RlOpenDev)));
         RL_HIP(hipHostMalloc((void**)&x.ctl, sizeof(RlOpenCtl), hipHostMallocCoherent | hipHostMallocMapped));
         RL_HIP(hipHostGetDevicePointer((void**)&x.ctl_dev, x.ctl, 0));

@@ -149,37 +149,38 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
 }
 
 // The conservative cull of rl_bound_pass() for the wave-uniform loops, in expanded form so that
-// everything ray-dependent is hoisted out of the loop (9 float ops + one compare per bound):
-//   d.(c - o)           = d.c + P,                    P = -d.o
-//   s (|c - o|^2 - R^2) = s w - 2 s o.c + s |o|^2,    w = |c|^2 - R^2 (table), s = 0.999 |d|^2
+// everything ray-dependent is hoisted out of the loop (8 float ops + one compare per bound):
+//   with s = 0.999 |d|^2 and D = d / sqrt(s):   D.(c - o) = D.c + P,        P = -D.o
+//   |c - o|^2 - R^2 = w - 2 o.c + |o|^2,                                    w = |c|^2 - R^2 (table)
 //   pass <=> origin inside the bound, or the ray reaches it ahead of the origin
-//        <=> max(d.co, 0)^2 - s (|co|^2 - R^2) >= 0
+//        <=> max(d.co, 0)^2 - s (|co|^2 - R^2) >= 0  <=>  max(D.co, 0)^2 - (w - 2 o.c) >= |o|^2
 // -- a single float compare, so the ballot reads the compare mask directly (a compound condition
 // would be materialised lane by lane first).  The expansion cancels, so the |o|^2 term carries a slack
 // of 1e-5 (|o|^2 + max|c|^2) -- more than 40x the worst rounding error 4 eps (|o|^2 + |c|^2) of either
-// product sum at any scene scale -- which only ever lets MORE pairs through.  This is the build's own
-// test (not reference arithmetic), so FMA is fine.  A lane without a path gets q = +inf and fails.
+// product sum at any scene scale -- which only ever lets MORE pairs through; the 0.999 in s covers the
+// roundings of D (an approximate rsqrt, three products).  This is the build's own test (not reference
+// arithmetic), so FMA is fine.  A lane without a path gets q = +inf and fails (its D is NaN: max(NaN, 0) = 0).
 struct RlCullRay {
-    RlF3 d;       // direction
+    RlF3 d;       // direction / sqrt(0.999 |direction|^2)
     float p;      // -d.o
-    RlF3 m;       // -2 s o
-    float s, q;   // s, s (|o|^2 - slack)
+    RlF3 m;       // -2 o
+    float q;      // |o|^2 - slack
 };
 __device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, bool idle) {
     RlCullRay r;
-    r.d = dir;
-    r.p = -(dir.x * o.x + dir.y * o.y + dir.z * o.z);
-    r.s = (dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f;
+    const float inv = __builtin_amdgcn_rsqf((dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f);
+    r.d = rl_f3(dir.x * inv, dir.y * inv, dir.z * inv);
+    r.p = -(r.d.x * o.x + r.d.y * o.y + r.d.z * o.z);
     const float o2 = o.x * o.x + o.y * o.y + o.z * o.z;
-    r.m = rl_f3(-2.0f * r.s * o.x, -2.0f * r.s * o.y, -2.0f * r.s * o.z);
-    r.q = idle ? __builtin_inff() : r.s * (o2 - 1.0e-5f * (o2 + cmax2));
+    r.m = rl_f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
+    r.q = idle ? __builtin_inff() : o2 - 1.0e-5f * (o2 + cmax2);
     return r;
 }
 __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
-    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, __builtin_fmaf(r.s, b.w, r.q))));
+    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
     const float ahead = __builtin_fmaxf(dd, 0.0f);
-    return __builtin_fmaf(ahead, ahead, -cs) >= 0.0f;
+    return __builtin_fmaf(ahead, ahead, -cs) >= r.q;
 }
 
 // Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
@@ -386,7 +387,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         r.d.x = __shfl(cr.d.x, (int)owner); r.d.y = __shfl(cr.d.y, (int)owner); r.d.z = __shfl(cr.d.z, (int)owner); \
         r.m.x = __shfl(cr.m.x, (int)owner); r.m.y = __shfl(cr.m.y, (int)owner); r.m.z = __shfl(cr.m.z, (int)owner); \
         r.p = __shfl(cr.p, (int)owner);                                                                 \
-        r.s = __shfl(cr.s, (int)owner);                                                                 \
         r.q = __shfl(cr.q, (int)owner);                                                                 \
         if (lane >= (COUNT)) r.q = __builtin_inff(); /* lanes beyond the round never pass */            \
         _Pragma("nounroll") for (uint32_t j = 0; j < RL_GROUP_G; ++j) {                                 \
