@@ -1,0 +1,56 @@
+"""Static properties of the compiled trace kernel that the design leans on (hipcc cross-compiles without a GPU):
+every variant of rl_trace_kernel fits 120 VGPRs -- at four waves per SIMD that leaves 32 of the 512 registers per lane,
+which is what lets PlotUnit::plot, GatherUnit::accumulate and the clears run BESIDE a resident (open) trace kernel
+instead of behind it (the behavioural check is tests/test_gpu_multi.py::test_small_kernels_run_beside...),
+the plain variants use no scratch memory, and the small kernels fit the registers that are left."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "robigo_luculenta_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+@pytest.fixture(scope="module")
+def usage(tmp_path_factory):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("no hipcc")
+    make = open(os.path.join(CSRC, "Makefile")).read()
+    flags = re.search(r"^FLAGS = (.*?)\n(?!\s)", make, re.S | re.M).group(1).replace("\\\n", " ")
+    flags = flags.replace("$(ARCH)", "gfx950").replace("$(EXTRA)", "").split()
+    out = str(tmp_path_factory.mktemp("res") / "k.o")
+    run = subprocess.run([HIPCC] + flags + ["-DRL_BUILD_ID=\"x\"", "--cuda-device-only", "-c", "-o", out, "rl_api.hip",
+                                            "-Rpass-analysis=kernel-resource-usage"], cwd=CSRC, capture_output=True, timeout=900)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    kernels, name = {}, None
+    for line in run.stderr.decode().splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+) \[", line)
+        if m and name:
+            kernels[name][m.group(1).strip()] = int(m.group(2))
+    assert kernels, run.stderr.decode()[-2000:]
+    return kernels
+
+
+def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage):
+    trace = {k: v for k, v in usage.items() if "rl_trace_kernel" in k}
+    assert len(trace) == 8                                            # LDS / global fetch x fused / un-fused x plain / open
+    for name, u in trace.items():
+        assert u["VGPRs"] <= 120 and u.get("AGPRs", 0) == 0, (name, u)
+        assert u["Occupancy"] == 4, (name, u)
+    plain = [u for k, u in trace.items() if k.endswith("Lb0EEvPK4RlF413RlSceneLayout10RlTraceJobP14RlMappedPhotonPfPyPK10RlJobEntryP9RlOpenDevP9RlOpenCtl")]
+    assert len(plain) == 4 and all(u["ScratchSize"] == 0 for u in plain), plain   # the bulk kernels spill nothing to memory
+
+
+def test_the_small_kernels_fit_beside_it(usage):
+    for needle in ("rl_plot_kernel", "rl_gather_kernel", "rl_add_kernel", "rl_tonemap_kernel"):
+        (u,) = [v for k, v in usage.items() if needle in k]
+        assert u["VGPRs"] <= 32, (needle, u)
