@@ -360,6 +360,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
         return off;
     };
     append(fs.spheres);
+    for (size_t pos = fs.cluster_base; pos < fs.spheres.size(); ++pos) blob[pos].w = fs.sphere_cull_w[pos]; // see RlSceneView::sphere_r2
     lay.off_planes = append(fs.planes);
     lay.off_parabs = append(fs.parabs);
     lay.off_prisms = append(fs.prisms);
@@ -374,6 +375,9 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     const size_t so_f4 = (fs.sphere_obj.size() + 3) / 4;
     blob.resize(blob.size() + so_f4);
     std::memcpy(blob.data() + lay.off_sphere_obj, fs.sphere_obj.data(), fs.sphere_obj.size() * sizeof(uint32_t));
+    lay.off_sphere_r2 = (uint32_t)blob.size();
+    blob.resize(blob.size() + so_f4);
+    for (size_t pos = 0; pos < fs.spheres.size(); ++pos) ((float*)(blob.data() + lay.off_sphere_r2))[pos] = fs.spheres[pos].w;
     lay.total_f4 = (uint32_t)blob.size();
     lay.n_direct = fs.n_direct;
     lay.n_direct_padded = fs.n_direct_padded;

@@ -38,6 +38,7 @@ struct RlSceneLayout {
     float cull_cmax2; // RlFlatScene::cull_cmax2
     uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
     uint32_t n_cluster_groups, n_prism_groups; // RlFlatScene: second level of the cull table
+    uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
 };
 
 struct RlTraceJob {
@@ -148,39 +149,85 @@ __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Cross-lane fetches of a round: every lane reads the values of its pair's owner lane.  The bpermutes are issued back to
+// back and waited for once -- the build's register-minimising scheduler otherwise issues them one at a time, each
+// followed by its own s_waitcnt and its first use (six to nine LDS round trips in a row at the head of every round; the
+// values are all live in the round's loop anyway, so nothing is saved by serialising them).
+__device__ __forceinline__ void rl_fetch6(uint32_t owner, float a0, float a1, float a2, float a3, float a4, float a5, float& r0, float& r1,
+                                          float& r2, float& r3, float& r4, float& r5) {
+    const uint32_t addr = owner << 2;
+    asm volatile("ds_bpermute_b32 %0, %6, %7\n\tds_bpermute_b32 %1, %6, %8\n\tds_bpermute_b32 %2, %6, %9\n\t"
+                 "ds_bpermute_b32 %3, %6, %10\n\tds_bpermute_b32 %4, %6, %11\n\tds_bpermute_b32 %5, %6, %12\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5)
+                 : "v"(addr), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5)
+                 : "memory");
+}
+__device__ __forceinline__ void rl_fetch3(uint32_t owner, float a0, float a1, float a2, float& r0, float& r1, float& r2) {
+    const uint32_t addr = owner << 2;
+    asm volatile("ds_bpermute_b32 %0, %3, %4\n\tds_bpermute_b32 %1, %3, %5\n\tds_bpermute_b32 %2, %3, %6\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+                 : "v"(addr), "v"(a0), "v"(a1), "v"(a2)
+                 : "memory");
+}
+
 // The conservative cull of rl_bound_pass() for the wave-uniform loops, in expanded form so that
 // everything ray-dependent is hoisted out of the loop (8 float ops + one compare per bound):
 //   with s = 0.999 |d|^2 and D = d / sqrt(s):   D.(c - o) = D.c + P,        P = -D.o
 //   |c - o|^2 - R^2 = w - 2 o.c + |o|^2,                                    w = |c|^2 - R^2 (table)
 //   pass <=> origin inside the bound, or the ray reaches it ahead of the origin
-//        <=> max(d.co, 0)^2 - s (|co|^2 - R^2) >= 0  <=>  max(D.co, 0)^2 - (w - 2 o.c) >= |o|^2
+//        <=> max(d.co, 0)^2 - s (|co|^2 - R^2) >= 0  <=>  (w - 2 o.c) - max(D.co, 0)^2 <= -|o|^2
 // -- a single float compare, so the ballot reads the compare mask directly (a compound condition
 // would be materialised lane by lane first).  The expansion cancels, so the |o|^2 term carries a slack
-// of 1e-5 (|o|^2 + max|c|^2) -- more than 40x the worst rounding error 4 eps (|o|^2 + |c|^2) of either
-// product sum at any scene scale -- which only ever lets MORE pairs through; the 0.999 in s covers the
+// of 2e-5 (|o|^2 + max|c|^2) -- several times the worst rounding error of the product sums and of the far-bound
+// terms below (each a few eps (|o|^2 + |c|^2) at any scene scale) -- which only ever lets MORE pairs through; the 0.999 in s covers the
 // roundings of D (an approximate rsqrt, three products).  This is the build's own test (not reference
-// arithmetic), so FMA is fine.  A lane without a path gets q = +inf and fails (its D is NaN: max(NaN, 0) = 0).
+// arithmetic), so FMA is fine.  A lane without a path gets q = -inf and fails (its D is NaN and so is the left-hand side).
 struct RlCullRay {
     RlF3 d;       // direction / sqrt(0.999 |direction|^2)
     float p;      // -d.o
     RlF3 m;       // -2 o
-    float q;      // |o|^2 - slack
+    float q;      // slack - |o|^2
+    float len;    // length of `direction` in the units of d.(c - o), rounded up: a hit at ray parameter t is t * len away
 };
 __device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, bool idle) {
     RlCullRay r;
-    const float inv = __builtin_amdgcn_rsqf((dir.x * dir.x + dir.y * dir.y + dir.z * dir.z) * 0.999f);
+    const float d2 = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
+    const float inv = __builtin_amdgcn_rsqf(d2 * 0.999f);
     r.d = rl_f3(dir.x * inv, dir.y * inv, dir.z * inv);
     r.p = -(r.d.x * o.x + r.d.y * o.y + r.d.z * o.z);
     const float o2 = o.x * o.x + o.y * o.y + o.z * o.z;
     r.m = rl_f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
-    r.q = idle ? __builtin_inff() : o2 - 1.0e-5f * (o2 + cmax2);
+    r.q = idle ? -__builtin_inff() : 2.0e-5f * (o2 + cmax2) - o2;
+    r.len = d2 * inv * 1.0001f;
     return r;
 }
-__device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b) {
+// `far` is the distance (in the units of RlCullRay::len) of the nearest hit the ray already has, rounded up: a bound
+// the ray enters farther away than that cannot hold the nearest hit, and a hit at exactly that distance (scene.rs:51
+// keeps the lower object index on a tie) lies inside its bound, i.e. not farther than where the ray enters it.
+//   f(x) = x^2 - 2 x D.co + (|co|^2 - R^2) is <= 0 exactly between the two points where the ray's line crosses the bound;
+//   with x = clamp(D.co, 0, far) -- the point of the segment [0, far] nearest to the bound's centre -- f(x) <= 0 says that
+//   the segment reaches the bound: for x = D.co it is the discriminant test above, for x = 0 "the origin is inside",
+//   for x = far "the entry point is not beyond the hit".  One v_med3 and one FMA more than the test without `far`.
+__device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b, float far) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
-    const float ahead = __builtin_fmaxf(dd, 0.0f);
-    return __builtin_fmaf(ahead, ahead, -cs) >= r.q;
+    const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
+    return __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs) <= r.q;
+}
+
+// The owner lane's cull terms (and far bound) for a round: nine values, one wait.
+__device__ __forceinline__ void rl_fetch_cull_ray(uint32_t owner, const RlCullRay& cr, float far, RlCullRay& r, float& r_far) {
+    const uint32_t addr = owner << 2;
+    asm volatile("ds_bpermute_b32 %0, %9, %10\n\tds_bpermute_b32 %1, %9, %11\n\tds_bpermute_b32 %2, %9, %12\n\t"
+                 "ds_bpermute_b32 %3, %9, %13\n\tds_bpermute_b32 %4, %9, %14\n\tds_bpermute_b32 %5, %9, %15\n\t"
+                 "ds_bpermute_b32 %6, %9, %16\n\tds_bpermute_b32 %7, %9, %17\n\tds_bpermute_b32 %8, %9, %18\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.d.x), "=&v"(r.d.y), "=&v"(r.d.z), "=&v"(r.m.x), "=&v"(r.m.y), "=&v"(r.m.z), "=&v"(r.p), "=&v"(r.q), "=&v"(r_far)
+                 : "v"(addr), "v"(cr.d.x), "v"(cr.d.y), "v"(cr.d.z), "v"(cr.m.x), "v"(cr.m.y), "v"(cr.m.z), "v"(cr.p), "v"(cr.q), "v"(far)
+                 : "memory");
+    r.len = 0.0f;
 }
 
 // Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
@@ -224,8 +271,8 @@ struct RlOpenWg {
 //     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2, uint32_t n_cluster_groups,
-                                              uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2,
+                                              uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
     RlLdsU64* keys = (RlLdsU64*)ws->key;
@@ -278,13 +325,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t e = ring_b[(b_head + lane) & 127u];
         const uint32_t owner = e & 63u;
         const uint32_t pos = e >> 6;
-        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
-        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
+        float ox, oy, oz, dx, dy, dz;
+        rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ox, oy, oz, dx, dy, dz);
         if (lane < count) {
             const RlF4 s = sph[pos];
             const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
             const float dd = dx * cox + dy * coy + dz * coz;
-            const float c = (cox * cox + coy * coy + coz * coz) - s.w;
+            const float c = (cox * cox + coy * coy + coz * coz) - sv.sphere_r2[pos]; // (a clustered sphere's s.w is its cull term)
             const float q = dd * dd - c;
             const float sq = sqrtf(q);
             const float t1 = dd - sq;
@@ -342,7 +389,15 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     }
     RL_T1(RL_ST_T_DIRECT, t_direct);
 
-    // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members ----
+    RL_T0(t_cluster);
+    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
+    // Far bound of the cull: the nearest hit so far -- here the planes, circles and paraboloids (in the built-in scene
+    // the floor, the walls and the ceiling: every ray has one), before the prisms also the spheres.
+    float far = best.t * cr.len;
+    // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members.  The members are
+    // tested with the cull's own arithmetic -- on the device a clustered sphere's record is {centre, |c|^2 - R^2}, see
+    // RlSceneView::sphere_r2 -- (8 FMAs, a v_med3 and a compare per member, far bound included) -- a conservative pre-test: ring B re-evaluates the pairs that pass with the
+    // reference's exact operations, so only "never drops a pair the reference would hit" matters here ----
     auto process_clusters = [&](uint32_t count) {
         RL_STAT(RL_ST_A_ROUNDS, 1);
         RL_STAT(RL_ST_A_LANES, count);
@@ -352,21 +407,29 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
         const uint32_t first = sv.cluster_base + RL_CLUSTER_STRIDE * (lane < count ? (e >> 6) : 0u) + 1u;
-        const float ox = __shfl(o.x, (int)owner), oy = __shfl(o.y, (int)owner), oz = __shfl(o.z, (int)owner);
-        const float dx = __shfl(dir.x, (int)owner), dy = __shfl(dir.y, (int)owner), dz = __shfl(dir.z, (int)owner);
-        const uint32_t not_mine = lane < count ? 0u : 0x80000000u; // lanes beyond the round never push
-        RlF4 s = sph[first];
+        RlCullRay r;
+        float r_far;
+        rl_fetch_cull_ray(owner, cr, far, r, r_far);
+        if (lane >= count) r.q = -__builtin_inff(); // lanes beyond the round never push
+        RlF4 mb = sph[first];
         for (uint32_t j = 0; j < RL_CLUSTER_K; ++j) {
-            const RlF4 s_next = sph[first + (j + 1 < RL_CLUSTER_K ? j + 1 : j)]; // one record of prefetch
-            RL_SPHERE_REJECT(s, first + j, owner, not_mine, ox, oy, oz, dx, dy, dz)
-            s = s_next;
+            const RlF4 mb_next = sph[first + (j + 1 < RL_CLUSTER_K ? j + 1 : j)]; // one record of prefetch
+            const bool cand = rl_cull_pass(r, mb, r_far);
+            const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
+            if (m != 0) {
+                if (cand) ring_b[(b_tail + rl_mbcnt(m)) & 127u] = ((first + j) << 6) | owner;
+                b_tail += (uint32_t)__popcll(m);
+                if (b_tail - b_head >= 64u) {
+                    process_spheres(64u);
+                    b_head += 64u;
+                }
+            }
+            mb = mb_next;
         }
         rl_wave_sync();
         RL_T1(RL_ST_T_A_ROUNDS, t_a);
     };
 
-    RL_T0(t_cluster);
-    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
     // The cull table (rl_scene.h): level-1 bounds [clusters | prisms], then one group bound per RL_GROUP_G of them.
     // Every ray is tested against the GROUP bounds with wave-uniform records; the (group, ray) pairs that pass are
     // compacted into ring S and a ring-S round tests the group's RL_GROUP_G members, one pair per lane with the
@@ -384,14 +447,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t owner = e & 63u;                                                                 \
         const uint32_t first = RL_GROUP_G * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
         RlCullRay r;                                                                                    \
-        r.d.x = __shfl(cr.d.x, (int)owner); r.d.y = __shfl(cr.d.y, (int)owner); r.d.z = __shfl(cr.d.z, (int)owner); \
-        r.m.x = __shfl(cr.m.x, (int)owner); r.m.y = __shfl(cr.m.y, (int)owner); r.m.z = __shfl(cr.m.z, (int)owner); \
-        r.p = __shfl(cr.p, (int)owner);                                                                 \
-        r.q = __shfl(cr.q, (int)owner);                                                                 \
-        if (lane >= (COUNT)) r.q = __builtin_inff(); /* lanes beyond the round never pass */            \
+        float r_far;                                                                                    \
+        rl_fetch_cull_ray(owner, cr, far, r, r_far);                                                    \
+        if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
         _Pragma("nounroll") for (uint32_t j = 0; j < RL_GROUP_G; ++j) {                                 \
             const RlF4 bnd = cull[first + j];                                                           \
-            const bool pass = rl_cull_pass(r, bnd);                                                     \
+            const bool pass = rl_cull_pass(r, bnd, r_far);                                              \
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
             if (m != 0) {                                                                               \
                 if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((first + j - (ITEM_BASE)) << 6) | owner; \
@@ -412,7 +473,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RlF4 g0 = gb[0];                                                                                \
         for (uint32_t g = 0; g < (N_GROUPS); ++g) {                                                     \
             const RlF4 g1 = gb[g + 1]; /* prefetch (the table has slack at its end) */                  \
-            const bool pass = rl_cull_pass(cr, g0);                                                     \
+            const bool pass = rl_cull_pass(cr, g0, far);                                                \
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
             if (m != 0) {                                                                               \
                 if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (((FIRST_GROUP) + g) << 6) | lane;    \
@@ -448,6 +509,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     b_head = b_tail;
     RL_T1(RL_ST_T_TAIL, t_tail);
     RL_T0(t_prism);
+    far = rl_u2f((uint32_t)(keys[lane] >> 32)) * cr.len; // every sphere has been merged by now (process_spheres ends in a wave sync)
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
     auto process_prisms = [&](uint32_t count) {
@@ -459,12 +521,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
         RlF3 ro, rd;
-        ro.x = __shfl(o.x, (int)owner);
-        ro.y = __shfl(o.y, (int)owner);
-        ro.z = __shfl(o.z, (int)owner);
-        rd.x = __shfl(dir.x, (int)owner);
-        rd.y = __shfl(dir.y, (int)owner);
-        rd.z = __shfl(dir.z, (int)owner);
+        rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
         if (lane < count) {
             const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * prism;
             const RlCand c = rl_hex_prism(pr, ro, rd);
@@ -540,6 +597,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     sv.objects = base + lay.off_objects;
     sv.cie = base + lay.off_cie;
     sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
+    sv.sphere_r2 = (const float*)(base + lay.off_sphere_r2);
     sv.n_direct = lay.n_direct;
     sv.n_direct_padded = lay.n_direct_padded;
     sv.cluster_base = lay.cluster_base;

@@ -679,5 +679,19 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     }
     fs.cull_bounds.push_back(dummy); // slack for the kernel's prefetch
     fs.cull_bounds.push_back(dummy);
+    // The clustered spheres in the cull's form: the fourth component a cluster-member record carries on the DEVICE
+    // instead of radius^2 (rl_api.hip swaps it in; the exact radius^2 goes to a separate float array that only the exact
+    // tail reads).  The cluster-member rounds of the kernel use it as a conservative pre-test -- the reference arithmetic
+    // (geometry.rs:204-240) runs afterwards, for the pairs that pass -- so the radius only has to cover the difference
+    // between the reference's float discriminant and the geometric one (the cull's own slack term does,
+    // rl_kernels.hip.h) plus a relative 1e-3.  Bound records, dummies and direct spheres get +inf: never reached.
+    fs.sphere_cull_w.assign(fs.spheres.size(), std::numeric_limits<float>::infinity());
+    for (size_t pos = fs.cluster_base; pos < fs.spheres.size(); ++pos) {
+        const RlF4& sp = fs.spheres[pos];
+        if (fs.sphere_obj[pos] == RL_HIT_NONE || !std::isfinite(sp.w) || !(sp.w >= 0.0f)) continue;
+        const double c2 = (double)sp.x * sp.x + (double)sp.y * sp.y + (double)sp.z * sp.z;
+        fs.sphere_cull_w[pos] = (float)(c2 - ((double)sp.w * 1.001 + 1.0e-6));
+        fs.cull_cmax2 = std::max(fs.cull_cmax2, (float)c2 * 1.0001f);
+    }
     return RL_OK;
 }

@@ -56,6 +56,10 @@ struct RlSceneView {
     const RlF4* prisms;
     const RlF4* objects;
     const uint32_t* sphere_obj;
+    // Device only: radius^2 per sphere record.  On the device a CLUSTERED sphere's record is {centre, |c|^2 - R^2} -- the form
+    // the cull test reads (rl_kernels.hip.h) -- and its exact radius^2 lives here; the host-side view keeps
+    // {centre, radius^2} everywhere and leaves this null.
+    const float* sphere_r2;
     const RlF4* cie; // RL_CIE_SAMPLES rows {X, Y, Z, 0}
     uint32_t n_planes, n_parabs, n_prisms, n_objects;
     uint32_t n_direct;         // direct spheres: records [0, n_direct)
@@ -80,6 +84,7 @@ struct RlFlatScene {
     // group's members.  Not in the reference; conservative like the bounds themselves.
     std::vector<RlF4> cull_bounds;
     uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [G * n_cluster_groups][G * n_prism_groups][groups][groups][slack]
+    std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView
@@ -89,7 +94,7 @@ struct RlFlatScene {
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).
     size_t staged_bytes() const {
         return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size() + camera_rec.size()) * sizeof(RlF4) +
-               sphere_obj.size() * sizeof(uint32_t);
+               sphere_obj.size() * (sizeof(uint32_t) + sizeof(float));
     }
 };
 

@@ -34,6 +34,7 @@ void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDe
     v.prisms = m->flat.prisms.data();
     v.objects = m->flat.objects.data();
     v.sphere_obj = m->flat.sphere_obj.data();
+    v.sphere_r2 = nullptr; // host view: every sphere record is {centre, radius^2}
     v.cie = (const RlF4*)RL_CIE1931_XYZ0;
     v.n_direct = m->flat.n_direct;
     v.n_direct_padded = m->flat.n_direct_padded;
