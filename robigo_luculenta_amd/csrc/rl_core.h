@@ -182,15 +182,7 @@ RL_HD float rl_plane_t(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* dn_out) {
 RL_HD bool rl_inside(RlF3 n, RlF3 off, RlF3 p) { return rl_dot(rl_sub(p, off), n) < 0.0f; }
 
 // geometry.rs:298-341: the distance only.
-RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir) {
-    const RlF3 origin = rl_sub(o, offset);
-    const RlF3 focal_offset = rl_sub(origin, focal_point);
-    const float n_dot_d = rl_dot(normal, dir);
-    const float n_dot_o = rl_dot(normal, origin);
-    const float d_dot_f = rl_dot(dir, focal_offset);
-    const float a = n_dot_d * n_dot_d - 1.0f;
-    const float b = 2.0f * n_dot_d * n_dot_o - 2.0f * d_dot_f;
-    const float c = n_dot_o * n_dot_o - rl_dot(focal_offset, focal_offset);
+RL_HD float rl_paraboloid_roots(float a, float b, float c) { // geometry.rs:316-341 given the quadratic's coefficients
     if (a == 0.0f) {
         const float t1 = -c / b;
         if (t1 < 0.0f) return -1.0f;
@@ -204,6 +196,31 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     if (p > 0.0f && (p < q || q < 0.0f)) return p;
     if (q > 0.0f) return q;
     return -1.0f;
+}
+RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir) {
+    const RlF3 origin = rl_sub(o, offset);
+    const RlF3 focal_offset = rl_sub(origin, focal_point);
+    const float n_dot_d = rl_dot(normal, dir);
+    const float n_dot_o = rl_dot(normal, origin);
+    const float d_dot_f = rl_dot(dir, focal_offset);
+    const float a = n_dot_d * n_dot_d - 1.0f;
+    const float b = 2.0f * n_dot_d * n_dot_o - 2.0f * d_dot_f;
+    const float c = n_dot_o * n_dot_o - rl_dot(focal_offset, focal_offset);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // One division instead of two.  For a < 0 (|normal.direction| < 1: every ray but one along the axis) dividing by a
+    // reverses the order and the signs of the two numerators np >= nq: p <= q, p > 0 iff np < 0, q > 0 iff nq < 0, so the
+    // reference's selection (geometry.rs:327-341) returns p when np < 0 (if p == q it returns q, the same number), else q
+    // when nq < 0, else nothing -- the quotient of ONE numerator, chosen by sign.  Signs survive the division unless a
+    // numerator is so small that half of it is no float (|n| < 2^-125, 0 excepted); those waves, and the ones holding a
+    // ray with a >= 0 or a NaN, take the literal form below (wave-uniform).
+    const float disc = b * b - 4.0f * a * c;
+    const float sq = sqrtf(disc);
+    const float np = -b + sq, nq = -b - sq;
+    const float pick = np < 0.0f ? np : nq;
+    const bool plain = a < 0.0f && (disc < 0.0f || ((fabsf(np) >= 1.0e-37f || np == 0.0f) && (fabsf(nq) >= 1.0e-37f || nq == 0.0f)));
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) return (disc < 0.0f || !(pick < 0.0f)) ? -1.0f : 0.5f * pick / a;
+#endif
+    return rl_paraboloid_roots(a, b, c);
 }
 
 // One candidate of a Compound: distance and which half-space.  Inside rl_hex_prism "None" is
@@ -273,6 +290,131 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     RlCand hit = rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
     if (!(hit.t < NONE)) hit.t = -1.0f;
     return hit;
+}
+
+// ---- the same result without walking the tree ----------------------------------------------------------------------
+// rl_hex_prism above costs ~600 instructions: 8 plane tests with an IEEE division each and 25 inside tests.  The prism
+// is a convex polytope, so the tree's answer is almost always the obvious one -- the last half-space the ray enters (if
+// it then still is inside all the others) or, from inside, the first one it leaves -- and whenever every decision the
+// tree would take is FAR from its threshold, that answer can be PROVED to be the tree's without evaluating the tree:
+//
+//   s_i(t) = n_i.(o + t d - off_i) = nm_i + t dn_i is what the tree's inside tests evaluate (rl_inside, < 0 = inside);
+//   t_k = -nm_k / dn_k (the reference's expression, geometry.rs:62) is where the ray crosses plane k: entering if
+//   dn_k < 0, leaving if dn_k > 0.  A candidate (a crossing with t_k > 0) reaches the root of the tree iff it passes the
+//   inside tests of all seven other half-spaces on its way up, and loses a pick only to a candidate that is not farther
+//   (rl_compound_pick).  With t_in = max entering t_k and t_out = min leaving t_k:
+//     hit:  t_out > max(t_in, 0).  k* = the entering plane of t_in if t_in > 0, else the leaving plane of t_out.  If
+//           (a) the point at t* is inside every other half-space j by a margin, |dn_j| |t_j - t*| > delta, and
+//           (b) every other candidate that is not farther than t* (an entering plane with 0 < t_j < t_in) is outside
+//               k*'s half-space by a margin when it gets there, |dn_k*| (t* - t_j) > delta,
+//           then k* passes all its tests, every candidate it meets in a pick is either None by then or strictly
+//           farther, and the tree returns (t_k*, k*).  Both conditions are min_j max(dn_j, dn_in) (t_j - t*) > delta.
+//     miss: t_out <= max(t_in, 0): every candidate has to pass the inside test of the entering plane e of t_in AND of
+//           the leaving plane x of t_out, and each fails one of them by a margin if (t_in - t_out) min(|dn_e|, dn_x) >
+//           2 delta (origin outside: candidates before the middle are outside e, the others outside x), or, from a
+//           point beyond plane x (t_in <= 0: no entering plane is a candidate), if the nearest candidate is:
+//           dn_x (t_min+ - t_out) > delta -- the margins only grow with t because |dn| >> the error per unit of t.
+//   delta bounds everything float arithmetic can do to such a test: the tree evaluates fl(n_i.(fl(o + fl(d t_j)) -
+//   off_i)) with t_j rounded; against nm_i + t_j dn_i (the float dot products taken as exact) that is off by at most
+//   27 u (|o| + |off| + |d| t) |n|, u = 2^-24, including the 17 u by which the t_k used HERE may be off: they come from
+//   v_rcp_f32 (1 ulp) instead of the division and carry the plane number in their low 3 bits (so that max / min return
+//   the plane with the value).  delta = 64 u (...) in 1-norms.  Signs are exact: t_k > 0 iff nm_k and dn_k differ in
+//   sign, in the reference's division and here alike; rays closer than 2^-16 |d| to parallel to a face, or with a
+//   crossing closer than 1e-30 to the origin, are not decided here.
+// Whatever is not decided by a margin -- near an edge, grazing, within delta of a face -- returns RL_PRISM_UNSURE and
+// the caller evaluates the tree (wave-uniformly on the GPU: a few per cent of the rounds).  A decided answer IS the
+// tree's answer, bit for bit: t is the reference's own division for plane k*.
+// pr[0].w holds max_k |off_k|_1 and pr[2].w max(1, max_k |n_k|_1) (rl_scene.cpp).
+enum { RL_PRISM_MISS = 0, RL_PRISM_HIT = 1, RL_PRISM_UNSURE = 2 };
+
+RL_HD float rl_rcp_approx(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x); // 1 ulp
+#elif defined(RL_TEST_RCP_NOISE)
+    // host mirror under test: a reciprocal that is off by up to one ulp in either direction, like the hardware's may be
+    const float r = 1.0f / x;
+    const uint32_t h = (rl_f2u(x) * 2654435761u) >> 30;
+    return h == 0 ? r : rl_u2f(rl_f2u(r) + (h == 1 ? 1u : h == 2 ? 0xffffffffu : 0u));
+#else
+    return 1.0f / x;
+#endif
+}
+
+RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
+    const float INF = __builtin_inff();
+    float dn[8], ta[8];
+    float t_in = -INF, t_out = INF;  // carry the plane number in their low 3 bits
+    float min_dn = INF, min_ta = INF;
+    uint32_t min_pos = 0xffffffffu;  // the smallest positive ta: positive floats order like their bits, negative ones are larger
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 8; ++k) {
+        const RlF3 n = rl_xyz(pr[2 * k]);
+        const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k + 1]));
+        const float dnk = rl_dot(n, d);   // exactly the reference's two dot products (geometry.rs:59-62)
+        const float nm = rl_dot(n, lo);
+        const float tk = rl_u2f((rl_f2u(-nm * rl_rcp_approx(dnk)) & 0xfffffff8u) | (uint32_t)k);
+        dn[k] = dnk;
+        ta[k] = tk;
+        const bool entering = dnk < 0.0f;
+        t_in = fmaxf(t_in, entering ? tk : -INF);
+        t_out = fminf(t_out, entering ? INF : tk);
+        min_dn = fminf(min_dn, fabsf(dnk));
+        min_ta = fminf(min_ta, fabsf(tk));
+        const uint32_t tb = rl_f2u(tk);
+        min_pos = tb < min_pos ? tb : min_pos;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // one plane at a time: without this the scheduler issues the sixteen record loads first and the round spills
+        asm volatile("" ::: "memory");
+#endif
+    }
+    const float U64 = 3.814697265625e-06f; // 64 * 2^-24
+    const float d1 = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
+    const float scale = U64 * pr[2].w;
+    const float s0 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + pr[0].w;
+    // not decided here: a ray nearly parallel to a face, a crossing at the origin (NaNs fail both compares)
+    bool sure = min_dn >= 1.52587890625e-05f * pr[2].w * d1 && min_ta >= 1.0e-30f;
+    const uint32_t k_e = rl_f2u(t_in) & 7u, k_x = rl_f2u(t_out) & 7u;
+    const float dn_e = rl_dot(rl_xyz(pr[2 * k_e]), d), dn_x = rl_dot(rl_xyz(pr[2 * k_x]), d); // = dn[k_e], dn[k_x]
+    const bool from_outside = t_in > 0.0f;
+    const float t0 = from_outside ? t_in : 0.0f;
+    const bool reaches = t_out > t0;
+    // hit: k* and the margins (a) and (b)
+    const uint32_t k_star = from_outside ? k_e : k_x;
+    const float t_star = from_outside ? t_in : t_out;
+    const float dn_in = from_outside ? dn_e : -INF;
+    float margin = INF;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; ++j) {
+        const float a = fmaxf(dn[j], dn_in) * (ta[j] - t_star);
+        margin = fminf(margin, ta[j] == t_star ? INF : a);
+    }
+    const bool hit_sure = margin > scale * (s0 + d1 * t_star);
+    // miss
+    const float gap = t0 - t_out;
+    const float t_first = (min_pos & 0x80000000u) ? INF : rl_u2f(min_pos);
+    const float miss_a = gap * fminf(fabsf(dn_e), dn_x), delta_a = 2.0f * scale * (s0 + d1 * fmaxf(t0, fabsf(t_out)));
+    const float miss_b = dn_x * (t_first - t_out), delta_b = scale * (s0 + d1 * t_first);
+    const bool miss_sure = from_outside ? miss_a > delta_a : (!(t_first < INF) || miss_b > delta_b);
+    sure = sure && (reaches ? hit_sure : miss_sure);
+    // the reference's own t for plane k* (geometry.rs:62)
+    const RlF3 n = rl_xyz(pr[2 * k_star]);
+    const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k_star + 1]));
+    out->t = -rl_dot(n, lo) / rl_dot(n, d);
+    out->k = k_star;
+    return !sure ? RL_PRISM_UNSURE : (reaches ? RL_PRISM_HIT : RL_PRISM_MISS);
+}
+
+// rl_hex_prism's result through the shortcut, the tree only where the shortcut does not decide.
+RL_HD RlCand rl_hex_prism_decided(const RlF4* pr, RlF3 o, RlF3 dir) {
+    RlCand c;
+    const int status = rl_hex_prism_fast(pr, o, dir, &c);
+    if (status == RL_PRISM_UNSURE) return rl_hex_prism(pr, o, dir);
+    if (status == RL_PRISM_MISS) c.t = -1.0f;
+    return c;
 }
 
 // Conservative cull (not in the reference) for a hexagonal prism or a sphere cluster: a valid hit
@@ -352,7 +494,7 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
     for (uint32_t i = 0; i < sv.n_prisms; ++i) {
         const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * i;
         if (!rl_bound_pass(pr[16], o, dir)) continue;
-        const RlCand c = rl_hex_prism(pr, o, dir);
+        const RlCand c = rl_hex_prism_decided(pr, o, dir);
         const uint32_t obj = rl_f2u(pr[1].w);
         if (c.t >= 0.0f && rl_nearer(c.t, obj, best)) {
             best.t = c.t;

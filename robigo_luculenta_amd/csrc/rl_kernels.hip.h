@@ -107,7 +107,7 @@ struct RlOpenCtl {
 enum { RL_ST_ITER, RL_ST_SCAN_LANES, RL_ST_A_ROUNDS, RL_ST_A_LANES, RL_ST_B_ROUNDS, RL_ST_B_LANES, RL_ST_P_ROUNDS, RL_ST_P_LANES,
        RL_ST_SHADE_DIFFUSE, RL_ST_SHADE_GLASS, RL_ST_SHADE_SOAP, RL_ST_END_EMITTER, RL_ST_END_VOID, RL_ST_ANY_GLASS, RL_ST_ANY_SOAP,
        RL_ST_ANY_COLOURED, RL_ST_ANY_GLOSSY, RL_ST_REFILLS, RL_ST_EMIT_BATCHES, RL_ST_EMIT_LANES, RL_ST_A_ITEMS, RL_ST_P_ITEMS,
-       RL_ST_ANY_DIFFUSE, RL_ST_S_ROUNDS, RL_ST_S_LANES, RL_ST_S_ITEMS,
+       RL_ST_ANY_DIFFUSE, RL_ST_S_ROUNDS, RL_ST_S_LANES, RL_ST_S_ITEMS, RL_ST_P_SLOW,
        // shader cycles (s_memtime) a wave spent in each region of the main loop, summed over waves
        RL_ST_T_TOTAL, RL_ST_T_REFILL, RL_ST_T_SMALL, RL_ST_T_DIRECT, RL_ST_T_CLUSTER, RL_ST_T_TAIL, RL_ST_T_PRISM, RL_ST_T_SHADE,
        RL_ST_T_EMIT, RL_ST_T_A_ROUNDS, RL_ST_T_B_ROUNDS, RL_ST_T_P_ROUNDS, RL_ST_T_CAMERA, RL_ST_T_S_ROUNDS, RL_ST_COUNT };
@@ -522,14 +522,22 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t prism = e >> 6;
         RlF3 ro, rd;
         rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
-        if (lane < count) {
-            const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * prism;
-            const RlCand c = rl_hex_prism(pr, ro, rd);
-            if (c.t >= 0.0f) {
-                const uint32_t obj = rl_f2u(pr[1].w);
-                const unsigned long long k = ((unsigned long long)rl_f2u(c.t) << 32) | (unsigned long long)((obj << 3) | c.k);
-                __hip_atomic_fetch_min(keys + owner, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
+        // The shortcut of rl_core.h decides all but ~0.1 % of the pairs (near an edge, grazing, within rounding of a face);
+        // a round that holds one of those evaluates the reference's Compound tree instead -- for every lane, the branch is
+        // wave-uniform, and with the same result for the lanes the shortcut had decided.
+        const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * (lane < count ? prism : 0u);
+        RlCand c;
+        int status = rl_hex_prism_fast(pr, ro, rd, &c);
+        if (lane >= count) status = RL_PRISM_MISS;
+        if (__builtin_amdgcn_ballot_w64(status == RL_PRISM_UNSURE) != 0) {
+            RL_STAT(RL_ST_P_SLOW, 1);
+            c = rl_hex_prism(pr, ro, rd);
+            status = (lane < count && c.t >= 0.0f) ? RL_PRISM_HIT : RL_PRISM_MISS;
+        }
+        if (status == RL_PRISM_HIT) {
+            const uint32_t obj = rl_f2u(pr[1].w);
+            const unsigned long long k = ((unsigned long long)rl_f2u(c.t) << 32) | (unsigned long long)((obj << 3) | c.k);
+            __hip_atomic_fetch_min(keys + owner, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         rl_wave_sync();
         RL_T1(RL_ST_T_P_ROUNDS, t_p);

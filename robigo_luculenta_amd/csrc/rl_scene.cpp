@@ -551,6 +551,16 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
             fs.prisms.push_back(F4(axis, 0.0f));
             fs.prisms.push_back(F4(rl_add(offset, rl_mul(axis, height)), objbits));
             fs.prisms.push_back(prism_bound(&fs.prisms[fs.prisms.size() - 16]));
+            { // scale constants of rl_hex_prism_fast (rl_core.h), in the unused fourth components of two normal records
+                RlF4* pr = &fs.prisms[fs.prisms.size() - RL_PRISM_STRIDE];
+                float off1 = 0.0f, n1 = 1.0f;
+                for (int k = 0; k < 8; ++k) {
+                    n1 = std::max(n1, std::fabs(pr[2 * k].x) + std::fabs(pr[2 * k].y) + std::fabs(pr[2 * k].z));
+                    off1 = std::max(off1, std::fabs(pr[2 * k + 1].x) + std::fabs(pr[2 * k + 1].y) + std::fabs(pr[2 * k + 1].z));
+                }
+                pr[0].w = off1 * 1.000001f;
+                pr[2].w = n1 * 1.000001f;
+            }
             break;
         }
         default:

@@ -25,6 +25,8 @@ def lib():
         L.mirror_builtin_desc.argtypes = [C.c_int, C.c_int, vp, u32, vp]
         L.mirror_render.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp, vp]
         L.mirror_plot.argtypes = [vp, u32, u32, vp, u64]
+        L.mirror_prism_fast_check.argtypes = [vp, u64, u64, vp]
+        L.mirror_prism_fast_check_paths.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
         _lib = L
     return _lib
 
@@ -54,6 +56,21 @@ class Scene:
         segs = C.c_uint64(0)
         lib().mirror_render(self.h, w, h, seed, stream, first, n, O.ptr(photons), C.byref(segs))
         return photons, segs.value
+
+
+def prism_fast_check(scene, trials, seed):
+    """rl_hex_prism_fast against rl_hex_prism on random and adversarial (prism, ray) pairs of `scene`:
+    {pairs, decided hits, decided misses, undecided, decided-but-different (must be 0), tree hits}."""
+    counts = np.zeros(6, dtype=np.uint64)
+    lib().mirror_prism_fast_check(scene.h, trials, seed, O.ptr(counts))
+    return dict(zip(("pairs", "hits", "misses", "undecided", "wrong", "tree_hits"), (int(c) for c in counts)))
+
+
+def prism_fast_check_paths(scene, w, h, seed, stream, first, n):
+    """The same comparison on the (prism, ray) pairs that paths [first, first + n) produce."""
+    counts = np.zeros(6, dtype=np.uint64)
+    lib().mirror_prism_fast_check_paths(scene.h, w, h, seed, stream, first, n, O.ptr(counts))
+    return dict(zip(("pairs", "hits", "misses", "undecided", "wrong", "tree_hits"), (int(c) for c in counts)))
 
 
 def plot(w, h, photons):

@@ -156,3 +156,140 @@ extern "C" uint32_t mirror_group_bounds(void* scene, float* out4, uint32_t cap, 
     }
     return n_groups;
 }
+
+// ---- rl_hex_prism_fast against the tree it replaces -----------------------------------------------------------------
+// Random and adversarial (prism, ray) pairs over the prisms of `scene`: rays from anywhere, rays that start on a face
+// (as after a refraction: origin = surface point + direction * 1e-5), rays aimed at edges and vertices, rays nearly
+// parallel to faces.  counts[0] = pairs, [1] = decided hits, [2] = decided misses, [3] = undecided, [4] = decided but
+// different from the tree (must be 0), [5] = tree hits.
+static inline uint64_t mix64(uint64_t& s) {
+    uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+static inline float unit01(uint64_t& s) { return (float)(mix64(s) >> 40) * (1.0f / 16777216.0f); }
+static inline float sym(uint64_t& s) { return unit01(s) * 2.0f - 1.0f; }
+
+extern "C" void mirror_prism_fast_check(void* scene, uint64_t trials, uint64_t seed, uint64_t* counts) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    const uint32_t n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
+    for (int i = 0; i < 6; ++i) counts[i] = 0;
+    if (n_prisms == 0) return;
+    uint64_t s = seed;
+    for (uint64_t it = 0; it < trials; ++it) {
+        const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * (mix64(s) % n_prisms)];
+        const RlF4 bound = pr[16];
+        if (!(bound.w > 0.0f) || !(bound.w < 1e30f)) continue; // a padding prism
+        const float R = std::sqrt(bound.w);
+        const RlF3 c = rl_xyz(bound);
+        auto rnd_dir = [&]() {
+            for (;;) {
+                RlF3 v = rl_f3(sym(s), sym(s), sym(s));
+                const float m = rl_dot(v, v);
+                if (m > 0.01f && m <= 1.0f) return rl_normalise(v);
+            }
+        };
+        // a point on the polytope's surface (or near it): start inside the bound, walk along a random ray with the tree
+        auto surface_point = [&](RlF3* p_out) {
+            for (int tries = 0; tries < 64; ++tries) {
+                const RlF3 o = rl_add(c, rl_mul(rnd_dir(), R * 2.0f));
+                const RlF3 target = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.3f));
+                const RlF3 d = rl_normalise(rl_sub(target, o));
+                const RlCand h = rl_hex_prism(pr, o, d);
+                if (h.t > 0.0f) {
+                    *p_out = rl_add(o, rl_mul(d, h.t));
+                    return true;
+                }
+            }
+            return false;
+        };
+        RlF3 o, d;
+        const uint32_t kind = (uint32_t)(mix64(s) % 6);
+        if (kind == 0) { // anywhere -> anywhere
+            o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 3.0f));
+            d = rnd_dir();
+        } else if (kind == 1) { // towards the prism
+            o = rl_add(c, rl_mul(rnd_dir(), R * (1.0f + 4.0f * unit01(s))));
+            d = rl_normalise(rl_sub(rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.5f)), o));
+        } else if (kind == 2 || kind == 3) { // from a face, as after a bounce: origin = surface point + dir * 1e-5 (trace_unit.rs:114)
+            RlF3 p;
+            if (!surface_point(&p)) continue;
+            d = rnd_dir();
+            if (kind == 3) d = rl_mul(d, 0.9f + 0.2f * unit01(s)); // glass leaves directions un-normalised
+            o = rl_add(p, rl_mul(d, 0.00001f));
+        } else if (kind == 4) { // aimed at an edge or a vertex: a surface point pushed onto the nearest other plane(s)
+            RlF3 p;
+            if (!surface_point(&p)) continue;
+            for (int pass = 0; pass < 2; ++pass) {
+                int best = -1;
+                float bd = 1e30f;
+                for (int k = 0; k < 8; ++k) {
+                    const float dist = std::fabs(rl_dot(rl_sub(p, rl_xyz(pr[2 * k + 1])), rl_xyz(pr[2 * k])));
+                    if (dist > 1e-4f && dist < bd) { bd = dist; best = k; }
+                }
+                if (best < 0) break;
+                const float sd = rl_dot(rl_sub(p, rl_xyz(pr[2 * best + 1])), rl_xyz(pr[2 * best]));
+                p = rl_sub(p, rl_mul(rl_xyz(pr[2 * best]), sd * (1.0f + 1e-6f * sym(s))));
+                if (mix64(s) & 1) break; // an edge; otherwise go on to a vertex
+            }
+            o = rl_add(c, rl_mul(rnd_dir(), R * (1.5f + 3.0f * unit01(s))));
+            d = rl_normalise(rl_sub(rl_add(p, rl_mul(rl_f3(sym(s), sym(s), sym(s)), 1e-5f * unit01(s) * unit01(s))), o));
+        } else { // nearly parallel to a face
+            const RlF3 n = rl_xyz(pr[2 * (mix64(s) % 8)]);
+            RlF3 t = rl_normalise(rl_cross(n, rnd_dir()));
+            d = rl_normalise(rl_add(t, rl_mul(n, 1e-4f * sym(s) * unit01(s))));
+            o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 1.5f));
+        }
+        const RlCand want = rl_hex_prism(pr, o, d);
+        RlCand got;
+        const int status = rl_hex_prism_fast(pr, o, d, &got);
+        counts[0] += 1;
+        if (want.t >= 0.0f) counts[5] += 1;
+        if (status == RL_PRISM_UNSURE) {
+            counts[3] += 1;
+        } else if (status == RL_PRISM_HIT) {
+            counts[1] += 1;
+            if (!(want.t >= 0.0f) || rl_f2u(want.t) != rl_f2u(got.t) || want.k != got.k) counts[4] += 1;
+        } else {
+            counts[2] += 1;
+            if (want.t >= 0.0f) counts[4] += 1;
+        }
+    }
+}
+
+// The same comparison on the (prism, ray) pairs a render actually produces: every segment of paths [first, first + n)
+// against every prism whose bound it passes.
+extern "C" void mirror_prism_fast_check_paths(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first,
+                                              uint64_t n, uint64_t* counts) {
+    const RlSceneView& sv = ((MirrorScene*)scene)->view;
+    const float aspect = (float)w / (float)h;
+    for (int i = 0; i < 6; ++i) counts[i] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        RlPath p;
+        rl_begin_path(sv, aspect, seed, stream, first + i, &p);
+        float value = 0.0f;
+        for (;;) {
+            for (uint32_t k = 0; k < sv.n_prisms; ++k) {
+                const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * k;
+                if (!rl_bound_pass(pr[16], p.origin, p.direction)) continue;
+                const RlCand want = rl_hex_prism(pr, p.origin, p.direction);
+                RlCand got;
+                const int status = rl_hex_prism_fast(pr, p.origin, p.direction, &got);
+                counts[0] += 1;
+                if (want.t >= 0.0f) counts[5] += 1;
+                if (status == RL_PRISM_UNSURE) counts[3] += 1;
+                else if (status == RL_PRISM_HIT) {
+                    counts[1] += 1;
+                    if (!(want.t >= 0.0f) || rl_f2u(want.t) != rl_f2u(got.t) || want.k != got.k) counts[4] += 1;
+                } else {
+                    counts[2] += 1;
+                    if (want.t >= 0.0f) counts[4] += 1;
+                }
+            }
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            uint32_t emitter = 0;
+            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value, &emitter) != RL_PATH_CONTINUES) break;
+        }
+    }
+}

@@ -155,3 +155,38 @@ def test_cull_table_is_conservative_by_construction():
             big = radii > 4 * np.median(radii)                     # the direct list
             assert inside_some[~big].all()
     assert checked > 150
+
+
+# ---- the prism shortcut (rl_hex_prism_fast) against the Compound tree it stands in for (geometry.rs:380-407) ----------
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_prism_shortcut_never_contradicts_the_compound_tree(which):
+    """Whatever rl_hex_prism_fast decides must be the tree's answer bit for bit (distance and half-space); what it
+    does not decide goes to the tree anyway.  Adversarial pairs: rays that start on a face (origin = hit + dir * 1e-5,
+    trace_unit.rs:114, un-normalised directions as glass leaves them), rays aimed at edges and vertices, rays nearly
+    parallel to faces -- with a reciprocal that is off by one ulp either way, as v_rcp_f32 may be (RL_TEST_RCP_NOISE)."""
+    objs, cam = M.builtin_desc(which)
+    sc = M.Scene(objs, cam)
+    r = M.prism_fast_check(sc, 3_000_000, 20260928 + which)
+    assert r["pairs"] > 2_000_000 and r["wrong"] == 0, r
+    assert r["hits"] > 0.3 * r["pairs"] and r["misses"] > 0.3 * r["pairs"], r   # it does decide both ways
+    assert r["undecided"] < 0.2 * r["pairs"], r                               # (adversarial mix: ~13 %)
+    p = M.prism_fast_check_paths(sc, 1280, 720, 3, 1, 5_000_000_000, 150_000)
+    assert p["pairs"] > 300_000 and p["wrong"] == 0, p
+    assert p["undecided"] < 0.003 * p["pairs"], p                             # real paths: ~0.1 %
+    assert abs(p["hits"] + p["undecided"] - p["tree_hits"]) <= p["undecided"], p
+
+
+def test_prism_shortcut_on_random_prisms():
+    """Randomly oriented, sized and placed prisms (tests/_random_scene.py), incl. far from the origin."""
+    import _random_scene as RS
+    for seed in (1, 2, 3, 4):
+        objs, cam = RS.random_scene(seed, n_spheres=40, n_prisms=12)
+        if seed == 4:   # far away from the origin: the margins scale with the coordinates
+            objs = objs.copy()
+            objs["v1"][objs["surface_kind"] == 4] += np.float32(900.0)
+        sc = M.Scene(objs, cam)
+        r = M.prism_fast_check(sc, 1_000_000, seed)
+        assert r["pairs"] > 500_000 and r["wrong"] == 0, (seed, r)
+        p = M.prism_fast_check_paths(sc, 640, 360, seed, 0, 0, 30_000)
+        assert p["wrong"] == 0, (seed, p)

@@ -15,7 +15,7 @@ from robigo_luculenta_amd import _lib  # noqa: E402
 
 NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_rounds", "p_lanes", "shade_diffuse",
          "shade_glass", "shade_soap", "end_emitter", "end_void", "any_glass", "any_soap", "any_coloured", "any_glossy",
-         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse", "s_rounds", "s_lanes", "s_items",
+         "refills", "emit_batches", "emit_lanes", "a_items", "p_items", "any_diffuse", "s_rounds", "s_lanes", "s_items", "p_slow",
          "t_total", "t_refill", "t_small", "t_direct", "t_cluster", "t_tail", "t_prism", "t_shade", "t_emit", "t_a_rounds",
          "t_b_rounds", "t_p_rounds", "t_camera", "t_s_rounds"]
 
@@ -40,6 +40,7 @@ print("  scan lanes active            %5.1f %%" % (100.0 * c["scan_lanes"] / (64
 for key, label in (("s", "group (ring S) rounds "), ("a", "cluster-member rounds"), ("b", "sphere-tail rounds    "), ("p", "prism CSG rounds     ")):
     r, l = c[key + "_rounds"], c[key + "_lanes"]
     print("  %s  %.2f per iteration, %4.1f %% of lanes filled" % (label, r / it, 100.0 * l / max(1, 64 * r)))
+print("  prism rounds that evaluated the Compound tree (the shortcut left a pair undecided): %.2f %%" % (100.0 * c["p_slow"] / max(1, c["p_rounds"])))
 print("  (cluster, ray) pairs         %.1f per iteration = %.2f per ray;  (prism, ray) pairs %.1f = %.2f per ray"
       % (c["a_items"] / it, c["a_items"] / float(c["scan_lanes"]), c["p_items"] / it, c["p_items"] / float(c["scan_lanes"])))
 hits = float(c["scan_lanes"])
