@@ -112,8 +112,6 @@ extern "C" {
     pub fn rl_scheduler_performance(s: *mut RlScheduler, mean: *mut f32, stddev: *mut f32) -> c_int;
     pub fn rl_app_run(config: *const RlAppConfig, stats: *mut RlAppStats, rgb_out: *mut u8) -> c_int;
 
-    pub fn rl_debug_batch_histogram(device: c_int, out: *mut u64) -> c_int;
-    pub fn rl_debug_math_probe(device: c_int, func: c_int, x: *const f32, y: *mut f32, n: u32) -> c_int;
 }
 
 pub fn check(rc: c_int) {

@@ -158,7 +158,7 @@ int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
  * the device if there is one (otherwise it starts one), and returns as soon as ITS paths are finished while the
  * kernel goes on with the other callers' -- so nothing is launched per call and the drain tail of one batch overlaps
  * the next batches.  The results are bit-identical to separate launches.  Path and segment counters are kept per
- * call; the kernel time of an open launch is credited to the first of its units asked for rl_trace_unit_stats. */
+ * call; the run time of an open launch is split among the units whose calls it carried, by paths, when it has ended. */
 int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                          uint64_t first_path_index);
 /* rl_trace_unit_render in two halves, for a host thread that has something else to do meanwhile (feeding other GPUs,
@@ -167,7 +167,10 @@ int rl_trace_unit_render(RlTraceUnit* unit, const RlScene* scene, uint64_t seed,
  * per unit at a time.  Everything that reads mapped_photons ends a begun render by itself: rl_plot_unit_plot (for the
  * units it plots), rl_trace_unit_photons, rl_trace_unit_sync, rl_trace_unit_stats, rl_trace_unit_destroy.  The thread
  * that ends a render need not be the one that began it, as long as the unit changes hands the way every unit must
- * (one user at a time, handed over through a lock or a channel -- the reference's Task does that). */
+ * (one user at a time, handed over through a lock or a channel -- the reference's Task does that).
+ * A device runs at most FOUR open launches at a time, one per (scene, seed, stream, image size, fetch mode, fused or not)
+ * combination in use.  A render begun for a fifth combination while begun-and-not-ended renders hold all four is not
+ * refused and does not wait: it gets a plain launch of its own on the unit's stream (same results; _end waits for it). */
 int rl_trace_unit_render_begin(RlTraceUnit* unit, const RlScene* scene, uint64_t seed, uint32_t stream,
                                uint64_t first_path_index);
 int rl_trace_unit_render_end(RlTraceUnit* unit);
@@ -378,18 +381,6 @@ typedef struct RlAppStats {
  * batches of its trace units as one launch over the next contiguous range), so the final image does not
  * depend on which worker or unit ran which task.  rgb_out (may be NULL) receives the last RGB8 image. */
 int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t* rgb_out);
-
-/* ---- diagnostics -------------------------------------------------------------------------------- */
-
-/* Not a reference interface: evaluates the shared numerics header (csrc/rl_math.h) on the GPU so a
- * test can check that the hipcc and g++ builds agree bit-for-bit.  fn: 0 sin, 1 cos, 2 tan, 3 exp,
- * 4 ln, 5 acos, 6 SF10 index of refraction (material.rs:203-213), 7 sqrt, 8 x[i] / x[i+1 mod n],
- * 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette decision (trace_unit.rs:122-125) for the triples
- * (x[i], x[m+i], x[2m+i]) = (rand, continue_chance, intensity), i < m = n / 3, result 1 or 0 in y[i]. */
-int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
-/* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
- * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
-int rl_debug_batch_histogram(int device, uint64_t* out);
 
 #ifdef __cplusplus
 }

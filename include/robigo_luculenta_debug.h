@@ -1,0 +1,32 @@
+/* robigo_luculenta_debug.h -- diagnostics of librobigo_luculenta.so.  NOT part of the drop-in boundary
+ * (include/robigo_luculenta.h): nothing here replaces a reference interface, a host never needs it, and the
+ * Rust binding (bindings/rust/ffi.rs) does not declare it.  Used by tests/, tools/ and the profiling scripts. */
+#ifndef ROBIGO_LUCULENTA_DEBUG_H
+#define ROBIGO_LUCULENTA_DEBUG_H
+#include "robigo_luculenta.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Evaluates the shared numerics header (csrc/rl_math.h) on the GPU so a test can check that the hipcc and
+ * g++ builds agree bit-for-bit.  fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 ln, 5 acos, 6 SF10 index of refraction
+ * (material.rs:203-213), 7 sqrt, 8 x[i] / x[i+1 mod n], 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette
+ * decision (trace_unit.rs:122-125) for the triples (x[i], x[m+i], x[2m+i]) = (rand, continue_chance,
+ * intensity), i < m = n / 3, result 1 or 0 in y[i]. */
+int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
+/* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
+ * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
+int rl_debug_batch_histogram(int device, uint64_t* out);
+/* The prism shortcut (csrc/rl_core.h: rl_hex_prism_fast) against the Compound tree it stands in for
+ * (geometry.rs:380-407), both evaluated ON THE GPU -- with the hardware's v_rcp_f32 -- for n rays against prism
+ * `prism` (0-based, in the scene's flattened order) of `scene`.  rays: n x {origin.xyz, direction.xyz}.
+ * out: n x {status (0 miss, 1 hit, 2 undecided), t bits and half-space of the shortcut, t bits (or 0xffffffff for
+ * "no hit") and half-space of the tree} as 5 uint32 each. */
+int rl_debug_prism_probe(const RlScene* scene, uint32_t prism, const float* rays, uint32_t n, uint32_t* out);
+/* Number of prism records of the scene's flattened form (padding prisms of the cull groups included). */
+int rl_debug_prism_count(const RlScene* scene, uint32_t* n_prisms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROBIGO_LUCULENTA_DEBUG_H */

@@ -385,3 +385,19 @@ def math_probe(fn, x, device=0):
     y = np.zeros_like(x)
     check(lib.rl_debug_math_probe(device, names[fn], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))
     return y
+
+
+def prism_probe(scene, prism, rays):
+    """rl_debug_prism_probe: the prism shortcut (rl_hex_prism_fast) and the Compound tree, both on the GPU, for `rays`
+    (n x 6: origin, direction) against prism number `prism` of the scene's flattened order.  Returns an (n, 5) uint32
+    array: status (0 miss, 1 hit, 2 undecided), shortcut {t bits, half-space}, tree {t bits or 0xffffffff, half-space}."""
+    rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+    out = np.zeros((len(rays), 5), dtype=np.uint32)
+    check(lib.rl_debug_prism_probe(scene.handle, int(prism), rays.ctypes.data_as(C.c_void_p), len(rays), out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def prism_count(scene):
+    n = C.c_uint32(0)
+    check(lib.rl_debug_prism_count(scene.handle, C.byref(n)))
+    return n.value

@@ -124,8 +124,13 @@ SIGNATURES = {
     "rl_scheduler_get_new_task": (_i, [_vp, C.POINTER(RlTask), _i64, C.POINTER(RlTask)]),
     "rl_scheduler_performance": (_i, [_vp, C.POINTER(_f), C.POINTER(_f)]),
     "rl_app_run": (_i, [C.POINTER(RlAppConfig), C.POINTER(RlAppStats), _vp]),
+}
+# include/robigo_luculenta_debug.h: diagnostics, not part of the drop-in boundary
+DEBUG_SIGNATURES = {
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
     "rl_debug_batch_histogram": (_i, [_i, _vp]),
+    "rl_debug_prism_probe": (_i, [_vp, _u32, _vp, _u32, _vp]),
+    "rl_debug_prism_count": (_i, [_vp, C.POINTER(_u32)]),
 }
 
 if not os.path.exists(LIB_PATH):
@@ -134,7 +139,7 @@ if not os.path.exists(LIB_PATH):
                       "or `make -C robigo_luculenta_amd/csrc` (hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
 
 lib = C.CDLL(LIB_PATH)
-for _name, (_res, _args) in SIGNATURES.items():
+for _name, (_res, _args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
     _fn = getattr(lib, _name)
     _fn.restype = _res
     _fn.argtypes = _args

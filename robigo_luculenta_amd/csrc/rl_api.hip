@@ -36,6 +36,7 @@
 #include <rccl/rccl.h> // types and prototypes only: the library is bound at run time (rccl_api below)
 
 #include "../../include/robigo_luculenta.h"
+#include "../../include/robigo_luculenta_debug.h"
 #include "rl_kernels.hip.h"
 #include "rl_scene.h"
 
@@ -86,11 +87,13 @@ struct RlScene {
 
 namespace {
 struct Session;
+enum { RL_SESSIONS_PINNED = 1000 }; // internal: session_begin found every open-launch slot held by begun renders
 
 // Paths and segments of a trace unit's calls that open launches served.  Shared with the tickets of the fused renders
 // begun on the unit, which are ended on other threads (whoever uses the plot unit next) and possibly after the unit is gone.
 struct UnitCounters {
     std::atomic<uint64_t> paths{0}, segments{0};
+    std::atomic<uint64_t> kernel_ns{0}; // the unit's share (by paths) of the open launches that carried its calls
 };
 
 // A blocking render that was begun and not yet ended.  The ticket of an un-fused render lives in its trace unit (whose
@@ -137,6 +140,7 @@ struct RlPlotUnit {
     hipEvent_t plotted; // recorded after the last plot kernel of a PlotUnit::plot call
     hipEvent_t ready;   // recorded on `stream` when a gather (or a reader on another stream) takes the buffer
     hipEvent_t cleared; // recorded on the gather stream after accumulate + clear
+    hipEvent_t tail;    // scratch: recorded on `stream` by a fused launch that has to start behind everything queued there
     Ticket ticket;      // rl_trace_unit_render_fused_begin: ended by whatever uses the buffer next (plot_settle)
 };
 
@@ -227,7 +231,12 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         RL_HIP(hipEventCreate(&ep.start));
         RL_HIP(hipEventCreate(&ep.stop));
     }
-    if (plot_unit) RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
+    if (plot_unit) {
+        RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->cleared, 0)); // the splat must not race the last gather's clear
+        // nor anything queued on the plot unit's own stream since (rl_plot_unit_add, the RCCL reduce, an upload)
+        RL_HIP(hipEventRecord(plot_unit->tail, plot_unit->stream));
+        RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->tail, 0));
+    }
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
@@ -408,7 +417,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
 }
 
 namespace {
-int sessions_quiesce(int device, double* ms);
+int sessions_quiesce(int device);
 int render_end(RlTraceUnit* u);
 int plot_settle(RlPlotUnit* plot);
 }
@@ -416,7 +425,7 @@ int plot_settle(RlPlotUnit* plot);
 int rl_scene_destroy(RlScene* scene) {
     if (!scene) return RL_OK;
     (void)hipSetDevice(scene->device);
-    (void)sessions_quiesce(scene->device, nullptr); // an open launch may still be reading the blob
+    (void)sessions_quiesce(scene->device); // an open launch may still be reading the blob
     (void)hipFree(scene->blob);
     delete scene;
     return RL_OK;
@@ -456,7 +465,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     if (e == hipSuccess) e = hipMemset(u->queue, 0, 3 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->rendered, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipDeviceSynchronize(); // the memsets above ran on the null stream
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // the memsets above ran on the null stream
     if (e != hipSuccess) {
         rl_trace_unit_destroy(u);
         return fail(RL_E_HIP, std::string("trace unit allocation: ") + hipGetErrorString(e));
@@ -536,6 +545,8 @@ struct Session {
     uint32_t stream_id = 0, width = 0, height = 0;
     int fetch = 0;
     bool fused = false;
+    // who the running kernel works for: (a unit's counters, paths of its call) per job; its run time is split by paths
+    std::vector<std::pair<std::shared_ptr<UnitCounters>, uint64_t>> shares;
 };
 
 struct DeviceSessions {
@@ -544,7 +555,6 @@ struct DeviceSessions {
     Session s[4];
     bool ready = false;
     uint64_t launches = 0;
-    double kernel_ms = 0.0; // of finished kernels, not yet credited to a trace unit (rl_trace_unit_stats)
     uint64_t histogram[RL_OPEN_CAP + 1] = {}; // finished kernels by number of calls they carried
     double presync_us = 0.0, admit_us = 0.0, wait_us = 0.0; // where the calls spent their time (RL_OPEN_LAUNCH_TIMING=1 prints it)
     uint64_t calls = 0, starts = 0;
@@ -585,7 +595,11 @@ int session_harvest(DeviceSessions* d, Session& x) {
     RL_HIP(hipStreamSynchronize(x.stream));
     float ms = 0.0f;
     RL_HIP(hipEventElapsedTime(&ms, x.start, x.stop));
-    d->kernel_ms += (double)ms;
+    uint64_t total = 0;
+    for (const auto& sh : x.shares) total += sh.second;
+    for (const auto& sh : x.shares) // every unit gets the part of the kernel's time that its paths are of the kernel's paths
+        if (total) sh.first->kernel_ns += (uint64_t)((double)ms * 1.0e6 * ((double)sh.second / (double)total));
+    x.shares.clear();
     d->launches += 1;
     const uint32_t carried = host_load(&x.ctl->final_at);
     d->histogram[carried <= RL_OPEN_CAP ? carried : 0] += 1;
@@ -594,16 +608,26 @@ int session_harvest(DeviceSessions* d, Session& x) {
     return RL_OK;
 }
 
-// Waits until no session kernel runs on `device`; their kernel time not yet credited to a unit is added to *ms.
-int sessions_quiesce(int device, double* ms) {
+// Waits until no session kernel runs on `device` and credits their run time to the units they worked for.  The waiting
+// happens OUTSIDE the device's lock: other threads' render calls go on being admitted meanwhile -- to the
+// kernels that are running, or to new ones, which this call then does not wait for.
+int sessions_quiesce(int device) {
     DeviceSessions* d = sessions_of(device);
+    hipStream_t streams[4];
+    int n = 0;
+    {
+        std::lock_guard<std::mutex> guard(d->lock);
+        if (!d->ready) return RL_OK;
+        for (Session& x : d->s)
+            if (x.launched) streams[n++] = x.stream;
+    }
+    for (int i = 0; i < n; ++i) RL_HIP(hipStreamSynchronize(streams[i]));
     std::lock_guard<std::mutex> guard(d->lock);
-    if (!d->ready) return RL_OK;
     for (Session& x : d->s) {
+        if (!x.launched || hipStreamQuery(x.stream) != hipSuccess) continue; // restarted meanwhile: its next harvest counts it
         const int rc = session_harvest(d, x);
         if (rc != RL_OK) return rc;
     }
-    if (ms) *ms += d->kernel_ms, d->kernel_ms = 0.0;
     return RL_OK;
 }
 
@@ -709,8 +733,14 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
     // What the call's target is still being read or cleared by (a plot of the unit's previous photons, the gather's
     // clear of the plot buffer) must be over before a kernel that is already running may write to it.
     const auto t0 = std::chrono::steady_clock::now();
-    if (plot) RL_HIP(hipEventSynchronize(plot->cleared));
-    else RL_HIP(hipStreamSynchronize(u->stream));
+    if (plot) {
+        RL_HIP(hipEventSynchronize(plot->cleared));
+        // ... and whatever else still reads or writes the buffer on the plot unit's own stream (rl_plot_unit_add, the RCCL
+        // reduce, an upload): a splat of the running kernel must not race them
+        RL_HIP(hipStreamSynchronize(plot->stream));
+    } else {
+        RL_HIP(hipStreamSynchronize(u->stream));
+    }
     const auto t1 = std::chrono::steady_clock::now();
     RlJobEntry e;
     e.target = plot ? (void*)plot->xyz : (void*)u->photons;
@@ -729,7 +759,7 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
                 if (x.open && x.n < RL_OPEN_CAP && x.scene == scene && x.seed == seed && x.stream_id == stream_id && x.width == u->width &&
                     x.height == u->height && x.fetch == u->fetch && x.fused == (plot != nullptr)) {
                     k = session_append(x, e);
-                    if (k >= 0) mine = &x, x.waiters += 1;
+                    if (k >= 0) mine = &x, x.waiters += 1, x.shares.emplace_back(u->counters, n_paths);
                     else x.open = false;
                     break;
                 }
@@ -742,6 +772,7 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
                     if (rc != RL_OK) return rc;
                     mine = &x;
                     x.waiters += 1;
+                    x.shares.emplace_back(u->counters, n_paths);
                     k = 0;
                     break;
                 }
@@ -749,7 +780,16 @@ int session_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64
             bool retry = false; // an open session that is full: close it to the host
             for (Session& x : d->s)
                 if (x.open && x.n >= RL_OPEN_CAP) x.open = false, retry = true;
-            if (!retry) d->changed.wait_for(guard, std::chrono::microseconds(50));
+            if (retry) continue;
+            // Every slot is taken by another (scene, seed, stream, size, fetch, fused) combination.  A slot nobody waits
+            // on frees itself (its kernel closes after a grace period), but one that carries begun renders stays until
+            // they are ended -- possibly by this very thread (a fifth combination begun without ending an
+            // earlier one used to spin here for ever).  If all of them do, the call gets a launch of its own instead.
+            bool all_pinned = true;
+            for (Session& x : d->s)
+                if (x.waiters == 0) all_pinned = false;
+            if (all_pinned) return RL_SESSIONS_PINNED;
+            d->changed.wait_for(guard, std::chrono::microseconds(50));
         }
     }
     Ticket& t = plot ? plot->ticket : u->ticket;
@@ -776,6 +816,7 @@ int session_end(Ticket& t) {
         const auto t3 = std::chrono::steady_clock::now();
         std::lock_guard<std::mutex> guard(d->lock);
         mine->waiters -= 1;
+        d->changed.notify_all(); // a slot may have become free for a thread waiting in session_begin
         d->presync_us += t.presync_us;
         d->admit_us += t.admit_us;
         d->wait_us += std::chrono::duration<double, std::micro>(t3 - t2).count();
@@ -804,8 +845,12 @@ int render_begin(RlTraceUnit* u, const RlScene* scene, RlPlotUnit* plot, uint64_
     if (scene->device != u->device) return fail(RL_E_STATE, "scene and trace unit live on different devices");
     if (first_path_index + n_paths < first_path_index || first_path_index + n_paths == ~0ull)
         return fail(RL_E_INVALID, "path indices must stay below 2^64 - 1");
-    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) return session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
-    // a ragged or a huge batch: a launch of its own on the unit's stream (a fused one is waited for by the plot unit's stream)
+    if (n_paths % 64 == 0 && n_paths < RL_SESSION_MAX_PATHS) {
+        rc = session_begin(u, scene, plot, seed, stream, first_path_index, n_paths);
+        if (rc != RL_SESSIONS_PINNED) return rc;
+    }
+    // a ragged or a huge batch, or no open launch to be had (rl_trace_unit_render_begin in robigo_luculenta.h): a launch of
+    // its own on the unit's stream (a fused one is waited for by the plot unit's stream)
     rc = launch_trace(u, scene, plot ? nullptr : u->photons, plot, seed, stream, first_path_index, n_paths);
     if (rc != RL_OK) return rc;
     Ticket& t = plot ? plot->ticket : u->ticket;
@@ -924,12 +969,12 @@ int rl_trace_unit_stats(RlTraceUnit* u, uint64_t* paths, uint64_t* segments, dou
     if ((rc = drain_events(u)) != RL_OK) return rc;
     unsigned long long q[3];
     RL_HIP(hipMemcpy(q, u->queue, sizeof q, hipMemcpyDeviceToHost));
-    // Calls served by open launches are counted per call (session_*); the kernel time of those launches, which serve
-    // many units at once, is credited to whichever unit asks first.
-    if ((rc = sessions_quiesce(u->device, &u->kernel_ms)) != RL_OK) return rc;
+    // Calls served by open launches are counted per call (session_*); the run time of such a launch, which serves many
+    // units at once, is split among them by paths when it has ended (session_harvest).
+    if ((rc = sessions_quiesce(u->device)) != RL_OK) return rc;
     if (segments) *segments = q[1] + u->counters->segments.load();
     if (paths) *paths = q[2] + u->counters->paths.load();
-    if (kernel_ms) *kernel_ms = u->kernel_ms;
+    if (kernel_ms) *kernel_ms = u->kernel_ms + (double)u->counters->kernel_ns.load() * 1.0e-6;
     return RL_OK;
 }
 
@@ -951,7 +996,7 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     u->owns = external_xyz == nullptr;
     u->cie = nullptr;
     u->stream = nullptr;
-    u->plotted = u->ready = u->cleared = nullptr;
+    u->plotted = u->ready = u->cleared = u->tail = nullptr;
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
     hipError_t e = hipSuccess;
     if (u->owns) {
@@ -964,7 +1009,8 @@ int rl_plot_unit_create(int device, uint32_t id, uint32_t width, uint32_t height
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->plotted, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->ready, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&u->cleared, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipDeviceSynchronize(); // the synchronous memsets / copies above ran on the null stream
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&u->tail, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // the synchronous memsets / copies above ran on the null stream
     if (e != hipSuccess) {
         rl_plot_unit_destroy(u);
         return fail(RL_E_HIP, std::string("plot unit allocation: ") + hipGetErrorString(e));
@@ -984,6 +1030,7 @@ int rl_plot_unit_destroy(RlPlotUnit* u) {
     if (u->plotted) (void)hipEventDestroy(u->plotted);
     if (u->ready) (void)hipEventDestroy(u->ready);
     if (u->cleared) (void)hipEventDestroy(u->cleared);
+    if (u->tail) (void)hipEventDestroy(u->tail);
     if (u->owns && u->xyz) (void)hipFree(u->xyz);
     if (u->cie) (void)hipFree(u->cie);
     delete u;
@@ -1050,7 +1097,7 @@ int rl_plot_unit_upload(RlPlotUnit* u, const RlVector3* in) {
     if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     RL_HIP(hipStreamSynchronize(u->stream));
     RL_HIP(hipMemcpy(u->xyz, in, (size_t)u->width * u->height * sizeof(RlVector3), hipMemcpyHostToDevice));
-    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipStreamSynchronize(nullptr)); // (the null stream only: a resident open trace kernel of another unit is not waited for)
     return RL_OK;
 }
 
@@ -1085,7 +1132,7 @@ int rl_gather_unit_create(int device, uint32_t width, uint32_t height, RlGatherU
     if (e == hipSuccess) e = hipMalloc((void**)&u->comp, bytes);
     if (e == hipSuccess) e = hipMemset(u->comp, 0, bytes);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&u->stream, getenv("RL_BLOCKING_STREAMS") ? hipStreamDefault : hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // (the null stream only: a resident open trace kernel of another unit is not waited for)
     if (e != hipSuccess) {
         rl_gather_unit_destroy(u);
         return fail(RL_E_HIP, std::string("gather unit allocation: ") + hipGetErrorString(e));
@@ -1177,7 +1224,7 @@ int rl_gather_unit_load(RlGatherUnit* u, const char* path) {
     std::fclose(f);
     RL_HIP(hipMemcpy(u->acc, host.data(), n * sizeof(RlVector3), hipMemcpyHostToDevice)); // the download above drained u->stream
     RL_HIP(hipMemcpy(u->comp, host.data() + n, n * sizeof(RlVector3), hipMemcpyHostToDevice));
-    RL_HIP(hipDeviceSynchronize());
+    RL_HIP(hipStreamSynchronize(nullptr)); // (the null stream only: a resident open trace kernel of another unit is not waited for)
     return RL_OK;
 }
 
@@ -1205,7 +1252,7 @@ int rl_tonemap_unit_create(int device, uint32_t width, uint32_t height, RlTonema
     if (e == hipSuccess) e = hipMemset(u->srgb, 0, n * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void**)&u->max_intensity, sizeof(float));
     if (e == hipSuccess) e = hipMemset(u->max_intensity, 0, sizeof(float));
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr); // (the null stream only: a resident open trace kernel of another unit is not waited for)
     if (e != hipSuccess) {
         rl_tonemap_unit_destroy(u);
         return fail(RL_E_HIP, std::string("tonemap unit allocation: ") + hipGetErrorString(e));
@@ -1471,7 +1518,7 @@ int rl_debug_batch_histogram(int device, uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
     for (uint32_t k = 0; k <= RL_OPEN_CAP; ++k) out[k] = 0;
     int rc = use_device(device);
-    if (rc == RL_OK) rc = sessions_quiesce(device, nullptr); // the open launches still running end first: then they are counted
+    if (rc == RL_OK) rc = sessions_quiesce(device); // the open launches still running end first: then they are counted
     if (rc != RL_OK) return rc;
     DeviceSessions* d = sessions_of(device);
     std::lock_guard<std::mutex> guard(d->lock);
@@ -1504,6 +1551,35 @@ int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n
     (void)hipFree(dx);
     if (dy) (void)hipFree(dy);
     if (e != hipSuccess) return fail(RL_E_HIP, std::string("math probe: ") + hipGetErrorString(e));
+    return RL_OK;
+}
+
+int rl_debug_prism_count(const RlScene* scene, uint32_t* n_prisms) {
+    if (!scene || !n_prisms) return fail(RL_E_INVALID, "null argument");
+    *n_prisms = scene->lay.n_prisms;
+    return RL_OK;
+}
+
+int rl_debug_prism_probe(const RlScene* scene, uint32_t prism, const float* rays, uint32_t n, uint32_t* out) {
+    if (!scene || !rays || !out) return fail(RL_E_INVALID, "null argument");
+    if (prism >= scene->lay.n_prisms) return fail(RL_E_INVALID, "no such prism");
+    if (n == 0) return RL_OK;
+    int rc = use_device(scene->device);
+    if (rc != RL_OK) return rc;
+    float* dr = nullptr;
+    uint32_t* dout = nullptr;
+    hipError_t e = hipMalloc((void**)&dr, (size_t)n * 6 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, (size_t)n * 5 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(dr, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rl_prism_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0,
+                           scene->blob + scene->lay.off_prisms + (size_t)RL_PRISM_STRIDE * prism, dr, n, dout);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 5 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (dr) (void)hipFree(dr);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(RL_E_HIP, std::string("prism probe: ") + hipGetErrorString(e));
     return RL_OK;
 }
 

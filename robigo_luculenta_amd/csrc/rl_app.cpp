@@ -166,19 +166,59 @@ int write_image(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) {
 // skipped on resume, never repeated.
 std::string sidecar_path(const char* checkpoint) { return std::string(checkpoint) + ".next"; }
 
+// Both files are replaced atomically (written beside themselves, then renamed), the index FIRST: a crash between the
+// two leaves a newer index beside an older buffer -- the samples in between are lost, which is noise, whereas the other
+// order would add them twice on resume, which is bias.
+int replace_file(const std::string& tmp, const std::string& path) { return std::rename(tmp.c_str(), path.c_str()) == 0 ? RL_OK : RL_E_IO; }
+
 int save_checkpoint(AppState& a) {
-    int rc = rl_gather_unit_save(a.gather, a.cfg->checkpoint);
-    if (rc != RL_OK) return rc;
     uint64_t next;
     {
         std::lock_guard<std::mutex> guard(a.lock_counters);
         next = a.first_batch + a.traces_issued;
     }
-    FILE* f = std::fopen(sidecar_path(a.cfg->checkpoint).c_str(), "w");
+    const std::string side = sidecar_path(a.cfg->checkpoint), side_tmp = side + ".tmp";
+    FILE* f = std::fopen(side_tmp.c_str(), "w");
     if (!f) return RL_E_IO;
     std::fprintf(f, "next_batch %llu\nphotons_per_batch %u\nseed %llu\nstream %u\nranks %zu\n", (unsigned long long)next, a.photons,
                  (unsigned long long)a.cfg->seed, a.cfg->stream, a.ranks.size());
-    return std::fclose(f) == 0 ? RL_OK : RL_E_IO;
+    if (std::fclose(f) != 0) return RL_E_IO;
+    int rc = replace_file(side_tmp, side);
+    if (rc != RL_OK) return rc;
+    const std::string buf = a.cfg->checkpoint, buf_tmp = buf + ".tmp";
+    rc = rl_gather_unit_save(a.gather, buf_tmp.c_str());
+    return rc != RL_OK ? rc : replace_file(buf_tmp, buf);
+}
+
+// Where a resumed run starts.  The sidecar records what the index counts (paths per batch) and which samples the buffer
+// holds (seed, first RNG stream, number of ranks = streams).  Same seed and the same streams: continue behind the recorded
+// path index, whatever the batch size is now.  Another seed, or streams the buffer has never seen: every sample is new,
+// the configured first_batch stands.  Same seed with streams that only partly overlap the recorded ones: some ranks
+// would repeat samples and others not -- refused.
+int resume_first_batch(const RlAppConfig* config, uint32_t photons, size_t ranks, uint64_t* first_batch, std::string* err) {
+    FILE* g = std::fopen(sidecar_path(config->checkpoint).c_str(), "r");
+    if (!g) return RL_OK; // a buffer without an index (a reference run's buffer.raw): nothing to continue from
+    unsigned long long next = 0, seed = 0;
+    unsigned ppb = 0, stream = 0;
+    size_t old_ranks = 0;
+    const int got = std::fscanf(g, "next_batch %llu photons_per_batch %u seed %llu stream %u ranks %zu", &next, &ppb, &seed, &stream, &old_ranks);
+    std::fclose(g);
+    if (got < 1) return RL_OK;
+    if (got < 5) { // an index written by an older build: batches of the current size, the current streams
+        ppb = photons, seed = config->seed, stream = config->stream, old_ranks = ranks;
+    }
+    if (seed != config->seed) return RL_OK;
+    const uint64_t lo = config->stream, hi = lo + ranks, olo = stream, ohi = olo + old_ranks;
+    if (hi <= olo || ohi <= lo) return RL_OK; // disjoint streams
+    if (lo != olo || hi != ohi) {
+        *err = "resume: the checkpoint holds RNG streams [" + std::to_string(olo) + ", " + std::to_string(ohi) + ") of this seed, the run asks for [" +
+               std::to_string(lo) + ", " + std::to_string(hi) + "): some ranks would repeat samples";
+        return RL_E_STATE;
+    }
+    const unsigned __int128 paths = (unsigned __int128)next * ppb;
+    const uint64_t batch = (uint64_t)((paths + photons - 1) / photons); // the first batch of the current size that starts behind them
+    if (batch > *first_batch) *first_batch = batch;
+    return RL_OK;
 }
 
 // App::execute_task (app.rs:113-126)
@@ -427,11 +467,8 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
             std::fclose(f);
             rc = rl_gather_unit_load(a.gather, config->checkpoint);
             // Continue where the checkpointed run stopped handing out batches (see save_checkpoint).
-            if (FILE* g = std::fopen(sidecar_path(config->checkpoint).c_str(), "r")) {
-                unsigned long long next = 0;
-                if (std::fscanf(g, "next_batch %llu", &next) == 1 && next > a.first_batch) a.first_batch = next;
-                std::fclose(g);
-            }
+            std::string why;
+            if (rc == RL_OK && (rc = resume_first_batch(config, a.photons, a.ranks.size(), &a.first_batch, &why)) != RL_OK) rl_internal_set_last_error(why);
         }
     }
     a.fused_next_path = a.first_batch * (uint64_t)a.photons;

@@ -645,8 +645,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     // and more) measured 15-35 % of the kernel's time -- the returning atomics queue up and stall the waves.
     // The results a count stands for must be visible to whatever kernel the host launches once the job is reported
     // complete.  They are written as agent-scope atomics (write-through stores, memory-side float adds), and a path
-    // is counted one iteration after its result was issued, behind an s_waitcnt vmcnt(0) (all that a workgroup-scope
-    // release is on this target; a release at agent scope would write the whole L2 back, buffer_wbl2, every time).
+    // is counted one iteration after its result was issued, behind an explicit s_waitcnt vmcnt(0) (settle() below; a release
+    // at agent scope would write the whole L2 back, buffer_wbl2, every time).
     uint32_t known_local = 0;          // wave-uniform: jobs known to this wave
     uint64_t pend_mask = 0;            // wave-uniform: lanes whose path finished in the last iteration (my_job is still theirs)
     uint32_t emit_pend = 0, emit_pend_base = 0; // wave-uniform: the emitter batch splatted in the last iteration
@@ -663,6 +663,11 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     // counts the paths whose results were issued an iteration ago
     auto settle = [&]() {
         if (pend_mask == 0 && emit_pend == 0) return;
+        // The results these counts stand for (write-through photon stores, memory-side float adds) must be acknowledged
+        // before the count can reach the host.  A workgroup-scope release fence compiles to a wait on the LDS counter only
+        // on this target (one variant reported paths before their stores had landed), so the wait on the
+        // vector-memory counter is spelled out; tests/test_kernel_resources.py looks for it in every OPEN variant.
+        asm volatile("s_waitcnt vmcnt(0) ; rl_settle: results acknowledged" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((pend_mask >> lane) & 1ull) __hip_atomic_fetch_add(wg_fin + my_job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane < emit_pend)
@@ -1287,4 +1292,20 @@ __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float*
     case 9: r = rl_powf(v, 1.0f / 2.4f); break;
     }
     y[i] = r;
+}
+
+// Diagnostics (robigo_luculenta_debug.h): the prism shortcut and the Compound tree for n rays against one prism of the scene.
+__global__ void rl_prism_probe_kernel(const RlF4* __restrict__ prisms, const float* __restrict__ rays, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RlF3 o = rl_f3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    const RlF3 d = rl_f3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    RlCand fast;
+    const int status = rl_hex_prism_fast(prisms, o, d, &fast);
+    const RlCand tree = rl_hex_prism(prisms, o, d);
+    out[5 * i] = (uint32_t)status;
+    out[5 * i + 1] = rl_f2u(fast.t);
+    out[5 * i + 2] = fast.k;
+    out[5 * i + 3] = tree.t >= 0.0f ? rl_f2u(tree.t) : 0xffffffffu;
+    out[5 * i + 4] = tree.k;
 }

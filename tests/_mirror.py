@@ -27,6 +27,8 @@ def lib():
         L.mirror_plot.argtypes = [vp, u32, u32, vp, u64]
         L.mirror_prism_fast_check.argtypes = [vp, u64, u64, vp]
         L.mirror_prism_fast_check_paths.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
+        L.mirror_prism_pairs.restype = u64
+        L.mirror_prism_pairs.argtypes = [vp, u64, u64, vp, vp, vp, u64]
         _lib = L
     return _lib
 
@@ -71,6 +73,15 @@ def prism_fast_check_paths(scene, w, h, seed, stream, first, n):
     counts = np.zeros(6, dtype=np.uint64)
     lib().mirror_prism_fast_check_paths(scene.h, w, h, seed, stream, first, n, O.ptr(counts))
     return dict(zip(("pairs", "hits", "misses", "undecided", "wrong", "tree_hits"), (int(c) for c in counts)))
+
+
+def prism_pairs(scene, trials, seed):
+    """The adversarial (prism, ray) pairs of prism_fast_check as data: prism numbers, rays (n x 6), the tree's {t bits, half-space}."""
+    prisms = np.zeros(trials, dtype=np.uint32)
+    rays = np.zeros((trials, 6), dtype=np.float32)
+    tree = np.zeros((trials, 2), dtype=np.uint32)
+    n = lib().mirror_prism_pairs(scene.h, trials, seed, O.ptr(prisms), O.ptr(rays), O.ptr(tree), trials)
+    return prisms[:n], rays[:n], tree[:n]
 
 
 def plot(w, h, photons):

@@ -171,76 +171,89 @@ static inline uint64_t mix64(uint64_t& s) {
 static inline float unit01(uint64_t& s) { return (float)(mix64(s) >> 40) * (1.0f / 16777216.0f); }
 static inline float sym(uint64_t& s) { return unit01(s) * 2.0f - 1.0f; }
 
+// One adversarial (prism, ray) pair; false when the draw has to be repeated.
+static bool gen_prism_pair(const RlFlatScene& fs, uint64_t& s, uint32_t* prism_out, RlF3* o_out, RlF3* d_out) {
+    const uint32_t n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
+    const uint32_t prism = (uint32_t)(mix64(s) % n_prisms);
+    const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * prism];
+    const RlF4 bound = pr[16];
+    if (!(bound.w > 0.0f) || !(bound.w < 1e30f)) return false; // a padding prism
+    const float R = std::sqrt(bound.w);
+    const RlF3 c = rl_xyz(bound);
+    auto rnd_dir = [&]() {
+        for (;;) {
+            RlF3 v = rl_f3(sym(s), sym(s), sym(s));
+            const float m = rl_dot(v, v);
+            if (m > 0.01f && m <= 1.0f) return rl_normalise(v);
+        }
+    };
+    // a point on the polytope's surface: a random ray from outside the bound, walked with the tree
+    auto surface_point = [&](RlF3* p_out) {
+        for (int tries = 0; tries < 64; ++tries) {
+            const RlF3 o = rl_add(c, rl_mul(rnd_dir(), R * 2.0f));
+            const RlF3 target = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.3f));
+            const RlF3 d = rl_normalise(rl_sub(target, o));
+            const RlCand h = rl_hex_prism(pr, o, d);
+            if (h.t > 0.0f) {
+                *p_out = rl_add(o, rl_mul(d, h.t));
+                return true;
+            }
+        }
+        return false;
+    };
+    RlF3 o, d;
+    const uint32_t kind = (uint32_t)(mix64(s) % 6);
+    if (kind == 0) { // anywhere -> anywhere
+        o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 3.0f));
+        d = rnd_dir();
+    } else if (kind == 1) { // towards the prism
+        o = rl_add(c, rl_mul(rnd_dir(), R * (1.0f + 4.0f * unit01(s))));
+        d = rl_normalise(rl_sub(rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.5f)), o));
+    } else if (kind == 2 || kind == 3) { // from a face, as after a bounce: origin = surface point + dir * 1e-5 (trace_unit.rs:114)
+        RlF3 p;
+        if (!surface_point(&p)) return false;
+        d = rnd_dir();
+        if (kind == 3) d = rl_mul(d, 0.9f + 0.2f * unit01(s)); // glass leaves directions un-normalised
+        o = rl_add(p, rl_mul(d, 0.00001f));
+    } else if (kind == 4) { // aimed at an edge or a vertex: a surface point pushed onto the nearest other plane(s)
+        RlF3 p;
+        if (!surface_point(&p)) return false;
+        for (int pass = 0; pass < 2; ++pass) {
+            int best = -1;
+            float bd = 1e30f;
+            for (int k = 0; k < 8; ++k) {
+                const float dist = std::fabs(rl_dot(rl_sub(p, rl_xyz(pr[2 * k + 1])), rl_xyz(pr[2 * k])));
+                if (dist > 1e-4f && dist < bd) { bd = dist; best = k; }
+            }
+            if (best < 0) break;
+            const float sd = rl_dot(rl_sub(p, rl_xyz(pr[2 * best + 1])), rl_xyz(pr[2 * best]));
+            p = rl_sub(p, rl_mul(rl_xyz(pr[2 * best]), sd * (1.0f + 1e-6f * sym(s))));
+            if (mix64(s) & 1) break; // an edge; otherwise go on to a vertex
+        }
+        o = rl_add(c, rl_mul(rnd_dir(), R * (1.5f + 3.0f * unit01(s))));
+        d = rl_normalise(rl_sub(rl_add(p, rl_mul(rl_f3(sym(s), sym(s), sym(s)), 1e-5f * unit01(s) * unit01(s))), o));
+    } else { // nearly parallel to a face
+        const RlF3 n = rl_xyz(pr[2 * (mix64(s) % 8)]);
+        RlF3 t = rl_normalise(rl_cross(n, rnd_dir()));
+        d = rl_normalise(rl_add(t, rl_mul(n, 1e-4f * sym(s) * unit01(s))));
+        o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 1.5f));
+    }
+    *prism_out = prism;
+    *o_out = o;
+    *d_out = d;
+    return true;
+}
+
 extern "C" void mirror_prism_fast_check(void* scene, uint64_t trials, uint64_t seed, uint64_t* counts) {
     const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
-    const uint32_t n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
     for (int i = 0; i < 6; ++i) counts[i] = 0;
-    if (n_prisms == 0) return;
+    if (fs.prisms.empty()) return;
     uint64_t s = seed;
     for (uint64_t it = 0; it < trials; ++it) {
-        const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * (mix64(s) % n_prisms)];
-        const RlF4 bound = pr[16];
-        if (!(bound.w > 0.0f) || !(bound.w < 1e30f)) continue; // a padding prism
-        const float R = std::sqrt(bound.w);
-        const RlF3 c = rl_xyz(bound);
-        auto rnd_dir = [&]() {
-            for (;;) {
-                RlF3 v = rl_f3(sym(s), sym(s), sym(s));
-                const float m = rl_dot(v, v);
-                if (m > 0.01f && m <= 1.0f) return rl_normalise(v);
-            }
-        };
-        // a point on the polytope's surface (or near it): start inside the bound, walk along a random ray with the tree
-        auto surface_point = [&](RlF3* p_out) {
-            for (int tries = 0; tries < 64; ++tries) {
-                const RlF3 o = rl_add(c, rl_mul(rnd_dir(), R * 2.0f));
-                const RlF3 target = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.3f));
-                const RlF3 d = rl_normalise(rl_sub(target, o));
-                const RlCand h = rl_hex_prism(pr, o, d);
-                if (h.t > 0.0f) {
-                    *p_out = rl_add(o, rl_mul(d, h.t));
-                    return true;
-                }
-            }
-            return false;
-        };
+        uint32_t prism;
         RlF3 o, d;
-        const uint32_t kind = (uint32_t)(mix64(s) % 6);
-        if (kind == 0) { // anywhere -> anywhere
-            o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 3.0f));
-            d = rnd_dir();
-        } else if (kind == 1) { // towards the prism
-            o = rl_add(c, rl_mul(rnd_dir(), R * (1.0f + 4.0f * unit01(s))));
-            d = rl_normalise(rl_sub(rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 0.5f)), o));
-        } else if (kind == 2 || kind == 3) { // from a face, as after a bounce: origin = surface point + dir * 1e-5 (trace_unit.rs:114)
-            RlF3 p;
-            if (!surface_point(&p)) continue;
-            d = rnd_dir();
-            if (kind == 3) d = rl_mul(d, 0.9f + 0.2f * unit01(s)); // glass leaves directions un-normalised
-            o = rl_add(p, rl_mul(d, 0.00001f));
-        } else if (kind == 4) { // aimed at an edge or a vertex: a surface point pushed onto the nearest other plane(s)
-            RlF3 p;
-            if (!surface_point(&p)) continue;
-            for (int pass = 0; pass < 2; ++pass) {
-                int best = -1;
-                float bd = 1e30f;
-                for (int k = 0; k < 8; ++k) {
-                    const float dist = std::fabs(rl_dot(rl_sub(p, rl_xyz(pr[2 * k + 1])), rl_xyz(pr[2 * k])));
-                    if (dist > 1e-4f && dist < bd) { bd = dist; best = k; }
-                }
-                if (best < 0) break;
-                const float sd = rl_dot(rl_sub(p, rl_xyz(pr[2 * best + 1])), rl_xyz(pr[2 * best]));
-                p = rl_sub(p, rl_mul(rl_xyz(pr[2 * best]), sd * (1.0f + 1e-6f * sym(s))));
-                if (mix64(s) & 1) break; // an edge; otherwise go on to a vertex
-            }
-            o = rl_add(c, rl_mul(rnd_dir(), R * (1.5f + 3.0f * unit01(s))));
-            d = rl_normalise(rl_sub(rl_add(p, rl_mul(rl_f3(sym(s), sym(s), sym(s)), 1e-5f * unit01(s) * unit01(s))), o));
-        } else { // nearly parallel to a face
-            const RlF3 n = rl_xyz(pr[2 * (mix64(s) % 8)]);
-            RlF3 t = rl_normalise(rl_cross(n, rnd_dir()));
-            d = rl_normalise(rl_add(t, rl_mul(n, 1e-4f * sym(s) * unit01(s))));
-            o = rl_add(c, rl_mul(rl_f3(sym(s), sym(s), sym(s)), R * 1.5f));
-        }
+        if (!gen_prism_pair(fs, s, &prism, &o, &d)) continue;
+        const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * prism];
         const RlCand want = rl_hex_prism(pr, o, d);
         RlCand got;
         const int status = rl_hex_prism_fast(pr, o, d, &got);
@@ -256,6 +269,27 @@ extern "C" void mirror_prism_fast_check(void* scene, uint64_t trials, uint64_t s
             if (want.t >= 0.0f) counts[4] += 1;
         }
     }
+}
+
+// The same pairs as data, for the device-side comparison (rl_debug_prism_probe): prism numbers, rays {o, d} and the g++
+// tree's answer {t bits or 0xffffffff, half-space}.  Returns the number of pairs written (<= cap).
+extern "C" uint64_t mirror_prism_pairs(void* scene, uint64_t trials, uint64_t seed, uint32_t* prisms, float* rays6, uint32_t* tree2, uint64_t cap) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    if (fs.prisms.empty()) return 0;
+    uint64_t s = seed, n = 0;
+    for (uint64_t it = 0; it < trials && n < cap; ++it) {
+        uint32_t prism;
+        RlF3 o, d;
+        if (!gen_prism_pair(fs, s, &prism, &o, &d)) continue;
+        const RlCand want = rl_hex_prism(&fs.prisms[RL_PRISM_STRIDE * prism], o, d);
+        prisms[n] = prism;
+        float* r = rays6 + 6 * n;
+        r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+        tree2[2 * n] = want.t >= 0.0f ? rl_f2u(want.t) : 0xffffffffu;
+        tree2[2 * n + 1] = want.k;
+        n += 1;
+    }
+    return n;
 }
 
 // The same comparison on the (prism, ray) pairs a render actually produces: every segment of paths [first, first + n)

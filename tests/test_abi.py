@@ -242,3 +242,16 @@ def test_scene_description_file_round_trip(tmp_path):
         R.load_scene_desc(path)
     with pytest.raises(R.RlError):
         R.load_scene_desc(str(tmp_path / "missing.rlsc"))
+
+
+def test_diagnostics_live_in_their_own_header_outside_the_boundary():
+    """rl_debug_* are exported for tests and tools but are not part of the drop-in boundary: declared in
+    include/robigo_luculenta_debug.h only, absent from the product header and from the Rust binding."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "robigo_luculenta_debug.h")).read(), flags=re.S)
+    debug = sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", text)))
+    assert debug and all(s.startswith("rl_debug_") for s in debug)
+    assert sorted(_lib.DEBUG_SIGNATURES) == debug
+    for s in debug:
+        assert hasattr(_lib.lib, s), "library does not export %s" % s
+    assert not [s for s in declared_symbols() if s.startswith("rl_debug_")]
+    assert "rl_debug_" not in open(os.path.join(ROOT, "bindings", "rust", "ffi.rs")).read()

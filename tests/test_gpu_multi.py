@@ -497,3 +497,73 @@ def test_app_with_many_workers_traces_every_path_exactly_once(R, fused, blocking
     _, segs = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam)).render(W, H, 9, 0, 0, batches * n, threads=8)
     assert st["batches"] == batches and st["paths"] == batches * n and st["segments"] == segs
     assert rgb.any()
+
+
+def test_a_fifth_combination_begun_without_ending_the_others_gets_a_launch_of_its_own(R):
+    """a device has four open-launch slots, one per (scene, seed, stream, size, fetch, fused) combination.
+    Renders begun for more combinations than that -- none ended yet, all on ONE thread -- used to spin for ever in the
+    fifth begin; now the fifth and sixth get plain launches.  Every result is still the oracle's."""
+    W, H, n = 64, 36, 1 << 12
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    units = [R.TraceUnit(i, W, H, n_photons=n) for i in range(6)]
+    done = []
+
+    def begin_all():
+        for i, u in enumerate(units):
+            u.render_begin(scene, seed=5, stream=i, first_path_index=100 * i)   # six streams = six combinations
+        done.append(True)
+
+    import threading
+    t = threading.Thread(target=begin_all, daemon=True)
+    t.start()
+    t.join(timeout=60)
+    assert done, "render_begin for a fifth combination did not return"
+    for i, u in reversed(list(enumerate(units))):
+        u.render_end()
+        want, segs = oscene.render(W, H, 5, i, 100 * i, n, threads=2)
+        assert u.mapped_photons.tobytes() == want.tobytes() and u.stats()[:2] == (n, segs), i
+
+
+def test_a_fused_render_waits_for_what_is_queued_on_its_plot_units_stream(R):
+    """rl_plot_unit_add leaves work on the destination's plot stream; a fused render begun into that buffer
+    right behind it (no clear, no accumulate in between) must splat AFTER the add, for plain and open launches."""
+    W, H, n = 96, 54, 1 << 14
+    objs, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    scene = R.Scene(objs, cam)
+    oscene = O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    a, b = O.plot(W, H, oscene.render(W, H, 2, 0, 0, n, threads=2)[0]), O.plot(W, H, oscene.render(W, H, 2, 0, n, n, threads=2)[0])
+    tr = R.TraceUnit(0, W, H, n_photons=64)
+    for sync_call in (False, True):
+        src, dst = R.PlotUnit(0, W, H), R.PlotUnit(1, W, H)
+        tr.render_fused(scene, src, n, seed=2, stream=0, first_path_index=0)
+        for _ in range(20):
+            dst.add(src)                                   # 20 x a on the plot stream
+            if sync_call:
+                tr.render_fused_sync(scene, dst, n, seed=2, stream=0, first_path_index=n)   # open launch
+            else:
+                tr.render_fused(scene, dst, n, seed=2, stream=0, first_path_index=n)        # plain launch
+        assert np.allclose(dst.tristimulus_buffer, 20.0 * (a + b), rtol=1e-4, atol=1e-6)
+
+
+def test_resume_converts_the_index_when_the_batch_size_changed_and_refuses_overlapping_streams(R, tmp_path):
+    """the sidecar's index counts batches of the size it was written with.  A resume with half the batch size
+    starts behind the same PATH index (not at the same batch number, which would repeat half the samples); a resume
+    whose RNG streams only partly overlap the checkpoint's is refused; another seed has nothing to continue from."""
+    W, H, n, N = 80, 45, 1 << 13, 6
+    raw = str(tmp_path / "buffer.raw")
+    kw = dict(concurrency=2, seed=9, fused=True)
+    _, st1 = R.app_run(W, H, N, checkpoint=raw, photons_per_batch=n, **kw)
+    assert not os.path.exists(raw + ".tmp") and not os.path.exists(raw + ".next.tmp")      # both files were renamed into place
+    assert open(raw + ".next").read().split() == ["next_batch", str(N), "photons_per_batch", str(n), "seed", "9", "stream", "0", "ranks", "1"]
+    rgb2, st2 = R.app_run(W, H, 2 * N, checkpoint=raw, resume=True, photons_per_batch=n // 2, **kw)
+    assert st2["next_batch"] == 2 * N + 2 * N                                              # started at batch 2N of the smaller size
+    rgb_once, st_once = R.app_run(W, H, 2 * N, photons_per_batch=n, **kw)
+    assert st1["segments"] + st2["segments"] == st_once["segments"]                        # the same paths, none twice
+    assert np.abs(rgb2.astype(int) - rgb_once.astype(int)).max() <= 1
+    with pytest.raises(R.RlError) as e:
+        R.app_run(W, H, 2, checkpoint=raw, resume=True, photons_per_batch=n, devices=[0, 0], concurrency=4, seed=9, fused=True)
+    assert "streams" in str(e.value)
+    _, st4 = R.app_run(W, H, 2, checkpoint=raw, resume=True, photons_per_batch=n, concurrency=2, seed=10, fused=True)
+    assert st4["next_batch"] == 2                                                          # a new seed: every sample is new

@@ -415,3 +415,30 @@ def test_full_size_properties_1080p(demo):
     assert not whole.tristimulus_buffer.any()
     g.accumulate(whole)
     assert g.tristimulus_buffer.tobytes() == before.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [R.SCENE_DEMO, R.SCENE_GLASS_STRESS])
+def test_prism_shortcut_on_the_device_never_contradicts_the_compound_tree(which):
+    """rl_hex_prism_fast with the hardware's v_rcp_f32 against the Compound tree (geometry.rs:380-407), both on the GPU
+    (rl_debug_prism_probe): whatever the shortcut decides is the tree's distance and half-space bit for bit, and the
+    device's tree is the g++ build's.  Adversarial pairs from tests/host_mirror (rays starting on faces, aimed at edges and
+    vertices, nearly parallel to faces)."""
+    import _mirror as M
+    objs, cam = R.builtin_scene_desc(which)
+    scene = R.Scene(objs, cam)
+    ms = M.Scene(objs.view(O.OBJECT_DTYPE), O.RlCameraDesc.from_buffer_copy(bytes(cam)))
+    prisms, rays, tree = M.prism_pairs(ms, 1_500_000, 77 + which)
+    assert len(prisms) > 1_000_000 and R.prism_count(scene) > prisms.max()
+    decided = undecided = 0
+    for p in np.unique(prisms):
+        sel = prisms == p
+        out = R.prism_probe(scene, p, rays[sel])
+        assert (out[:, 3:5][out[:, 3] != 0xffffffff] == tree[sel][tree[sel][:, 0] != 0xffffffff]).all()   # same tree on both sides
+        assert ((out[:, 3] == 0xffffffff) == (tree[sel][:, 0] == 0xffffffff)).all()
+        hit, miss = out[:, 0] == 1, out[:, 0] == 0
+        assert (out[hit, 1] == out[hit, 3]).all() and (out[hit, 2] == out[hit, 4]).all()   # a decided hit: the tree's t and half-space
+        assert (out[miss, 3] == 0xffffffff).all()                                          # a decided miss: the tree misses
+        decided += int(hit.sum() + miss.sum())
+        undecided += int((out[:, 0] == 2).sum())
+    assert decided > 0.75 * len(prisms) and undecided > 0   # it decides most pairs, and the adversarial ones reach the tree

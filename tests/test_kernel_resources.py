@@ -37,11 +37,16 @@ def usage(tmp_path_factory):
         if m and name:
             kernels[name][m.group(1).strip()] = int(m.group(2))
     assert kernels, run.stderr.decode()[-2000:]
+    asm = out[:-2] + ".s"   # the same compilation as text, for the checks that read instructions
+    run = subprocess.run([HIPCC] + flags + ["-DRL_BUILD_ID=\"x\"", "--cuda-device-only", "-S", "-o", asm, "rl_api.hip"], cwd=CSRC,
+                         capture_output=True, timeout=900)
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    kernels["__asm__"] = open(asm).read()
     return kernels
 
 
 def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage):
-    trace = {k: v for k, v in usage.items() if "rl_trace_kernel" in k}
+    trace = {k: v for k, v in usage.items() if "rl_trace_kernel" in k and k != "__asm__"}
     assert len(trace) == 8                                            # LDS / global fetch x fused / un-fused x plain / open
     for name, u in trace.items():
         assert u["VGPRs"] <= 120 and u.get("AGPRs", 0) == 0, (name, u)
@@ -52,5 +57,20 @@ def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage
 
 def test_the_small_kernels_fit_beside_it(usage):
     for needle in ("rl_plot_kernel", "rl_gather_kernel", "rl_add_kernel", "rl_tonemap_kernel"):
-        (u,) = [v for k, v in usage.items() if needle in k]
+        (u,) = [v for k, v in usage.items() if needle in k and k != "__asm__"]
         assert u["VGPRs"] <= 32, (needle, u)
+
+
+def test_open_variants_wait_for_their_results_before_counting_them(usage):
+    """Open launches report a path complete one iteration after its result was issued; the count may only follow the
+    acknowledgement of the stores / float adds (s_waitcnt vmcnt(0)).  The compiler's workgroup-scope release does not
+    emit that wait on gfx950, so settle() spells it out -- in every OPEN variant (inside settle(), so at every
+    site it is inlined or merged into), and in none of the plain ones (which never count per call)."""
+    text = usage["__asm__"]
+    bodies = {}
+    for m in re.finditer(r"\n(_Z15rl_trace_kernelILb[01]ELb[01]ELb([01])E\w+):(.*?)s_endpgm", text, re.S):
+        bodies[m.group(1)] = (m.group(2) == "1", m.group(3))
+    assert len(bodies) == 8
+    for name, (is_open, body) in bodies.items():
+        n = len(re.findall(r"s_waitcnt vmcnt\(0\) ; rl_settle", body))
+        assert (n >= 1) if is_open else (n == 0), (name, n)   # (the compiler may merge settle()'s call sites into one)
