@@ -200,6 +200,8 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.n_paths = n_paths;
     job.grace_ticks = 0;
     job.reserved = 0;
+    job.wm1 = (float)(int)u->width - 1.0f;
+    job.hm1 = (float)(int)u->height - 1.0f;
 
     // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
@@ -653,6 +655,8 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     static const uint32_t grace_us = getenv("RL_OPEN_LAUNCH_GRACE_US") ? (uint32_t)atoi(getenv("RL_OPEN_LAUNCH_GRACE_US")) : 150u;
     job.grace_ticks = grace_us * 100u; // ticks of wall_clock64() (100 MHz) an idle open launch waits for another call
     job.reserved = 0;
+    job.wm1 = (float)(int)u->width - 1.0f;
+    job.hm1 = (float)(int)u->height - 1.0f;
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
     const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
     auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)

@@ -711,10 +711,13 @@ struct RlSplat {
     float w[4];      // c11 c21 c12 c22
 };
 
-RL_HD RlSplat rl_splat_weights(uint32_t width, uint32_t height, float aspect_ratio, float x, float y) {
+// wm1 = (float)width - 1.0f and hm1 = (float)height - 1.0f are passed in: plot_unit.rs:60-61 computes them per photon, the
+// trace kernel gets them with its launch parameters (scalar registers) -- evaluated per call they were hoisted out of
+// the persistent loop into two vector registers that then spilled.
+RL_HD RlSplat rl_splat_weights(uint32_t width, uint32_t height, float wm1, float hm1, float aspect_ratio, float x, float y) {
     const int w = (int)width, h = (int)height;
-    const float px = (x * 0.5f + 0.5f) * ((float)w - 1.0f);
-    const float py = (y * aspect_ratio * 0.5f + 0.5f) * ((float)h - 1.0f);
+    const float px = (x * 0.5f + 0.5f) * wm1;
+    const float py = (y * aspect_ratio * 0.5f + 0.5f) * hm1;
     int px1 = (int)floorf(px), px2 = (int)ceilf(px), py1 = (int)floorf(py), py2 = (int)ceilf(py);
     px1 = px1 < 0 ? 0 : (px1 > w - 1 ? w - 1 : px1);
     px2 = px2 < 0 ? 0 : (px2 > w - 1 ? w - 1 : px2);
@@ -732,4 +735,7 @@ RL_HD RlSplat rl_splat_weights(uint32_t width, uint32_t height, float aspect_rat
     s.idx[2] = (uint32_t)(py2 * w + px1);
     s.idx[3] = (uint32_t)(py2 * w + px2);
     return s;
+}
+RL_HD RlSplat rl_splat_weights(uint32_t width, uint32_t height, float aspect_ratio, float x, float y) {
+    return rl_splat_weights(width, height, (float)(int)width - 1.0f, (float)(int)height - 1.0f, aspect_ratio, x, y);
 }

@@ -50,6 +50,7 @@ struct RlTraceJob {
     uint64_t n_paths;        // plain launch: number of paths
     uint32_t grace_ticks;    // open launch: how long (10 ns ticks) it waits for another call once every call is complete
     uint32_t reserved;
+    float wm1, hm1;          // (float)width - 1, (float)height - 1 (plot_unit.rs:60-61): see rl_splat_weights
 };
 
 // One call of an open launch: its path offsets [0, end) are the path indices first_path .. of the call's RNG stream and
@@ -648,7 +649,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     // is counted one iteration after its result was issued, behind an explicit s_waitcnt vmcnt(0) (settle() below; a release
     // at agent scope would write the whole L2 back, buffer_wbl2, every time).
     uint32_t known_local = 0;          // wave-uniform: jobs known to this wave
-    uint64_t pend_mask = 0;            // wave-uniform: lanes whose path finished in the last iteration (my_job is still theirs)
+    bool pend_me = false;              // this lane's path finished in the last iteration (my_job is still its job)
+    bool pend_any = false;             // wave-uniform: some lane's did
     uint32_t emit_pend = 0, emit_pend_base = 0; // wave-uniform: the emitter batch splatted in the last iteration
     RlOpenWg* wgp = (RlOpenWg*)(scratch + RL_TRACE_BLOCK / 64);
     RlLdsU32* wg_fin = (RlLdsU32*)&wgp->fin[0];
@@ -662,18 +664,19 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     }
     // counts the paths whose results were issued an iteration ago
     auto settle = [&]() {
-        if (pend_mask == 0 && emit_pend == 0) return;
+        if (!pend_any && emit_pend == 0) return;
         // The results these counts stand for (write-through photon stores, memory-side float adds) must be acknowledged
         // before the count can reach the host.  A workgroup-scope release fence compiles to a wait on the LDS counter only
         // on this target (one variant reported paths before their stores had landed), so the wait on the
         // vector-memory counter is spelled out; tests/test_kernel_resources.py looks for it in every OPEN variant.
         asm volatile("s_waitcnt vmcnt(0) ; rl_settle: results acknowledged" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if ((pend_mask >> lane) & 1ull) __hip_atomic_fetch_add(wg_fin + my_job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (pend_me) __hip_atomic_fetch_add(wg_fin + my_job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane < emit_pend)
             __hip_atomic_fetch_add(wg_fin + (rl_f2u(emit[4 * 128 + ((emit_pend_base + lane) & 127u)]) >> 24), 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
-        pend_mask = 0;
+        pend_me = false;
+        pend_any = false;
         emit_pend = 0;
     };
     // reports the workgroup's counts to RlOpenDev if nobody did in the last `gap` ticks; whoever completes a job tells the host
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
-                const RlSplat sp = rl_splat_weights(job.width, job.height, job.aspect_ratio, sx, sy);
+                const RlSplat sp = rl_splat_weights(job.width, job.height, job.wm1, job.hm1, job.aspect_ratio, sx, sy);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float* px = target + 3ull * sp.idx[k];
@@ -1032,7 +1035,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         }
         if (OPEN) {
             // a path that ended on a light is finished when it is splatted (process_emitted), every other one now
-            pend_mask = __builtin_amdgcn_ballot_w64(ended_now && !(FUSED && ended_on_emitter));
+            pend_me = ended_now && !(FUSED && ended_on_emitter);
+            pend_any = __builtin_amdgcn_ballot_w64(pend_me) != 0;
             ended_now = false;
         }
         RL_T1(RL_ST_T_SHADE, t_shade);

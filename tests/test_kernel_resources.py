@@ -2,7 +2,7 @@
 every variant of rl_trace_kernel fits 120 VGPRs -- at four waves per SIMD that leaves 32 of the 512 registers per lane,
 which is what lets PlotUnit::plot, GatherUnit::accumulate and the clears run BESIDE a resident (open) trace kernel
 instead of behind it (DESIGN.md 5; the behavioural check is tests/test_gpu_multi.py::test_small_kernels_run_beside...),
-the plain variants use no scratch memory, and the small kernels fit the registers that are left."""
+no variant uses scratch memory, and the small kernels fit the registers that are left."""
 import os
 import re
 import shutil
@@ -51,8 +51,13 @@ def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage
     for name, u in trace.items():
         assert u["VGPRs"] <= 120 and u.get("AGPRs", 0) == 0, (name, u)
         assert u["Occupancy"] == 4, (name, u)
-    plain = [u for k, u in trace.items() if k.endswith("Lb0EEvPK4RlF413RlSceneLayout10RlTraceJobP14RlMappedPhotonPfPyPK10RlJobEntryP9RlOpenDevP9RlOpenCtl")]
-    assert len(plain) == 4 and all(u["ScratchSize"] == 0 for u in plain), plain   # the bulk kernels spill nothing to memory
+    # nothing spills to memory in ANY variant -- the OPEN ones are what the drop-in's blocking calls run --
+    # and the scalar registers that do not fit (launch constants, written once to lanes of a vector register and read
+    # back where they are used) stay bounded: the LDS variants have 32-bit scene addresses, the global ones 64-bit
+    for name, u in trace.items():
+        assert u["ScratchSize"] == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
+        lds, is_open = "ILb1E" in name, "Lb1EEvPK4RlF4" in name
+        assert u["SGPRs Spill"] <= (40 if lds and not is_open else 56 if lds else 72), (name, u)
 
 
 def test_the_small_kernels_fit_beside_it(usage):
