@@ -9,8 +9,11 @@ One "step" = `--launches-per-step` (8) fused TraceUnit::render + PlotUnit::plot 
 GatherUnit step: with N > 1 the ranks' XYZ plot buffers are summed onto rank 0 by the library's own RCCL exchange
 (rl_plot_unit_reduce: one ncclReduce over xGMI), rank 0 Kahan-accumulates and every rank clears
 (gather_unit.rs:49-64, app.rs:147).  Every rank renders the full frame with its own RNG stream (stream = rank) --
-samples shard, nothing else is exchanged -- so per-GPU work is fixed as N grows ("weak").  A ray = one
-Scene::intersect call (one path segment, scene.rs:39), counted on the device.  Rank 0 prints ONE JSON line.
+samples shard, nothing else is exchanged -- so per-GPU work is fixed as N grows ("weak"); `--total-paths T` fixes the
+paths of a step for the whole job instead and splits them over the ranks ("strong").  A ray = one
+Scene::intersect call (one path segment, scene.rs:39), counted on the device.  Rank 0 prints ONE JSON line; with
+N > 1 it says what the exchange ran on (`config.rccl`: the communicator size and version RCCL itself reports) and
+what it cost (`exchange`: device time of the ncclReduce per step, max over ranks).
 
 torch is not used for device work at all: N = 1 never imports it, and N > 1 uses torch.distributed (gloo) only for
 the control plane (communicator id, barriers, max/sum of timings; robigo_luculenta_amd/distributed.py).
@@ -32,10 +35,6 @@ BATCH = 1024 * 512  # trace_unit.rs:67
 # (SURVEY 8d): sphere 19, paraboloid 38, plane / circle / half-space 14.
 FLOPS_SPHERE, FLOPS_PARABOLOID, FLOPS_PLANE = 19, 38, 14
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
-# Wave64 VALU issue interval of a plain mul/add/sub stream (the op mix the reference arithmetic allows) at the trace
-# kernel's occupancy of 4 waves per SIMD, measured in shader cycles: profiles/r02_valu_microbench.txt ("mul/add/sub
-# mix", w/SIMD = 4, wall c/i).  MI355X_MICROARCH.md's nominal figure is 2.
-MEASURED_STREAM_CYCLES_4_WAVES = 2.7
 
 CONFIGS = {
     # name: (scene, param, width, height)
@@ -77,29 +76,87 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(objs, cam, width, height, seconds_target=30.0):
-    """Times the CPU oracle (C++ restatement of the Rust reference, built -O3 without fast-math; the Rust crate
-    cannot be built here: no rustc/cargo) on this box's host cores over a bounded sample of the same workload:
-    >= 30 s on every usable core, then ~3 s on one thread."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import _oracle as O
-    threads = usable_cores()
-    scene = O.Scene(objs.view(O.OBJECT_DTYPE), O.RlCameraDesc.from_buffer_copy(bytes(cam)))
+def cpu_app(R, O, scene, width, height, workers, max_batches, seed=1):
+    """The reference's App on the host: `workers` threads (app.rs:66-70) take tasks from ONE TaskScheduler
+    (task_scheduler.rs:91-182 -- csrc/rl_scheduler.cpp through the C ABI, host code) under a mutex (app.rs:57,107) and
+    execute them with the CPU oracle's units outside it: Trace = 524,288 paths into the unit's mapped_photons
+    (trace_unit.rs:151-168), Plot, Gather (Kahan + clear), Tonemap, Sleep = 100 ms (app.rs:113-164).  Stops handing out
+    Trace tasks after `max_batches`; returns (rays of the completed Trace tasks, paths, seconds, tasks by kind)."""
     import ctypes as C
+    import threading
+    import numpy as np
+    sched = R.TaskScheduler(workers, tonemap_interval_ms=30000)
+    n_trace, n_plot = 3 * workers, max(1, workers // 2)       # task_scheduler.rs:95-96
+    photons = [np.zeros(BATCH, dtype=O.PHOTON_DTYPE) for _ in range(n_trace)]
+    plots = [np.zeros((width * height, 3), np.float32) for _ in range(n_plot)]
+    acc, comp = np.zeros((width * height, 3), np.float32), np.zeros((width * height, 3), np.float32)
+    lock = threading.Lock()
+    state = {"issued": 0, "done": 0, "rays": 0, "tasks": [0] * 5}
+    t0 = time.perf_counter()
+
+    def worker():
+        task = R.Task()
+        while True:
+            with lock:
+                task = sched.get_new_task(task, int((time.perf_counter() - t0) * 1000))
+                batch = None
+                if task.kind == R.TASK_TRACE:
+                    if state["issued"] >= max_batches:
+                        return                      # the budget is handed out: this worker is done (its unit stays taken)
+                    batch = state["issued"]
+                    state["issued"] += 1
+                state["tasks"][task.kind] += 1
+            if task.kind == R.TASK_TRACE:
+                segs = C.c_uint64(0)
+                O.lib().oracle_render(scene.h, width, height, seed, 0, batch * BATCH, BATCH, O.ptr(photons[task.unit]), C.byref(segs))
+                with lock:
+                    state["done"] += 1
+                    state["rays"] += segs.value
+            elif task.kind == R.TASK_PLOT:
+                for u in task.units:
+                    O.plot(width, height, photons[u], plots[task.unit])
+            elif task.kind == R.TASK_GATHER:
+                for u in task.units:
+                    O.accumulate(acc, comp, plots[u])
+                    plots[u][:] = 0.0
+            elif task.kind == R.TASK_TONEMAP:
+                O.tonemap(acc, width, height)
+            else:
+                time.sleep(0.1)                     # app.rs:129
+
+    threads = [threading.Thread(target=worker) for _ in range(workers)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    return state["rays"], state["done"] * BATCH, time.perf_counter() - t0, state["tasks"]
+
+
+def cpu_baseline(R, objs, cam, width, height, seconds_target=30.0):
+    """SURVEY 8(d)'s CPU baseline: the CPU oracle (C++ restatement of the Rust reference, built -O3 without fast-math;
+    the Rust crate cannot be built here: no rustc / cargo) driven like the reference drives its own units -- the
+    TaskScheduler with concurrency = the host's usable cores and 524,288-path Trace tasks -- for >= ~30 s at the bench's
+    resolution, plus BASELINE config 1 (256x256, ONE worker, seed 1) time-boxed to two of its 128 batches."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import _oracle as O
+    workers = usable_cores()
+    scene = O.Scene(objs.view(O.OBJECT_DTYPE), O.RlCameraDesc.from_buffer_copy(bytes(cam)))
     segs = C.c_uint64(0)
-    # calibrate on a small slice, then size the sample for ~seconds_target
-    n0 = 20000 * threads
-    dt0 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, 0, n0, None, C.byref(segs), threads)
-    n = int(max(n0, min(n0 * seconds_target * 1.05 / max(dt0, 1e-3), 256 * BATCH)))
-    dt = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0, n, None, C.byref(segs), threads)
-    segs1 = C.c_uint64(0)
-    n1 = max(20000, int(n / threads * 3.0 / max(dt, 1e-3)))
-    dt1 = O.lib().oracle_render_mt(scene.h, width, height, 1, 0, n0 + n, n1, None, C.byref(segs1), 1)
-    return {"value": segs.value / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "one_thread": {"value": segs1.value / dt1 / 1e6, "unit": "Mrays/s", "sample": "%d paths, %.1f s" % (n1, dt1)},
-            "sample": "%d camera paths (%d rays) of the same scene/resolution, seed 1, %d threads, %.1f s; oracle built -O3"
-                      % (n, segs.value, threads, dt),
-            "mpaths_per_s": n / dt / 1e6, "batches_per_s": n / dt / BATCH}
+    t = time.perf_counter()
+    import numpy as np
+    scratch = np.zeros(20000, dtype=O.PHOTON_DTYPE)
+    O.lib().oracle_render(scene.h, width, height, 1, 0, 1 << 40, 20000, O.ptr(scratch), C.byref(segs))   # calibrate one thread
+    per_path = (time.perf_counter() - t) / 20000.0
+    batches = max(workers, int(seconds_target * workers / (per_path * BATCH) + 0.5))
+    rays, paths, dt, tasks = cpu_app(R, O, scene, width, height, workers, batches)
+    rays1, paths1, dt1, tasks1 = cpu_app(R, O, scene, 256, 256, 1, 2)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": workers, "kind": "port", "scheduler": True,
+            "sample": "%d Trace tasks of %d paths (%d rays) of the same scene / resolution through the TaskScheduler with %d workers "
+                      "(tasks Sleep/Trace/Plot/Gather/Tonemap = %s), seed 1, %.1f s; oracle built -O3" % (paths // BATCH, BATCH, rays, workers, tasks, dt),
+            "mpaths_per_s": paths / dt / 1e6, "batches_per_s": paths / dt / BATCH,
+            "config1": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1, "batches_per_s": paths1 / dt1 / BATCH,
+                        "sample": "BASELINE config 1 (built-in scene, 256x256, scheduler concurrency 1, seed 1) time-boxed: %d of its 128 "
+                                  "batches (%d rays), %.1f s" % (paths1 // BATCH, rays1, dt1)},
+            "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "sample": "the config-1 run"}}
 
 
 def scene_of(R, config):
@@ -117,7 +174,7 @@ def scene_of(R, config):
     return objs, cam, W, H, label
 
 
-def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms):
+def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_per_launch=None):
     """The counter-derived half of the roofline, from the newest committed profiles/*_pmc.json that was measured
     on THIS build of the library and this workload (rl_build_id: a hash of the device code's sources).  The
     counters cannot be read from inside the process, so they come from the rocprofv3 --pmc passes of this same
@@ -148,7 +205,6 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms):
         "valu_insts_per_64ray_segment": c["SQ_INSTS_VALU"] / segs64,
         "cycles_per_valu_inst_per_simd": cyc,
         "issue_frac_vs_2cyc": 2.0 / cyc,
-        "issue_frac_vs_measured_stream": MEASURED_STREAM_CYCLES_4_WAVES / cyc,
         "active_lanes": lanes,
         "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
         "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
@@ -156,8 +212,10 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms):
         "wave_time": ({"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                        "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]} if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None),
         "profiled_launch_ms": d["kernel_ns"] / 1e6, "profiled_rays_per_launch": d["rays_per_launch"],
-        # the same workload: launches of the same size over other path ranges differ by a few ppm in ray count
-        "rays_per_launch_match": abs(d["rays_per_launch"] - rays_per_launch) <= 1e-3 * rays_per_launch,
+        # the same workload: rays per path of the profiled launch and of this run's launches (other path ranges, possibly
+        # another launch size) agree to a few ppm
+        "rays_per_path_match": abs(d["rays_per_launch"] / d["paths_per_launch"] - rays_per_launch / paths_per_launch) <= 2e-3 * rays_per_launch / paths_per_launch
+                               if paths_per_launch else None,
     }
     traffic = None
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -189,7 +247,12 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
     f_seg = flops_per_ray(objs)
     launch_ms = (ms1 - ms0) / launches
     achieved = (s1 - s0) / launches * f_seg / (launch_ms * 1e-3) / 1e12
-    return {"config": config, "workload": "built-in %s scene (%d objects), %dx%d, primitives in %s, %d launches of %d batches"
+    ex = executed_from_profile(R, config, fetch, (s1 - s0) / launches, launch_ms, n)
+    executed = ex[0] if isinstance(ex, tuple) else ex
+    if not executed.get("stale"):   # the short form: what SURVEY 8(d) asks for per config (VALUUtilization = active lanes)
+        executed = {k: executed[k] for k in ("profile", "build_id", "valu_insts_per_64ray_segment", "cycles_per_valu_inst_per_simd",
+                                              "issue_frac_vs_2cyc", "active_lanes", "useful_lane_slots_vs_2cyc")}
+    return {"config": config, "executed": executed, "workload": "built-in %s scene (%d objects), %dx%d, primitives in %s, %d launches of %d batches"
             % (label, len(objs), W, H, "LDS" if fetch == "lds" else "global/scalar cache", launches, batches_per_launch),
             "value": (s1 - s0) / (t1 - t0) / 1e6, "unit": "Mrays/s", "mpaths_per_s": (p1 - p0) / (t1 - t0) / 1e6,
             "kernel_ms_per_launch": launch_ms, "algorithmic_flops_per_ray": f_seg,
@@ -243,6 +306,35 @@ def spawn_ranks(args):
         raise SystemExit("bench.py: rank exit codes %r" % (rcs,))
 
 
+def rccl_report(world, rccl_used, info, sum_worlds, backend):
+    """`config.rccl` of an N > 1 line: did RCCL see N ranks?  `world` is what every rank's communicator reports
+    (ncclCommCount), summed over the ranks by the control plane and divided by N -- N iff all of them say N."""
+    return {"world": sum_worlds / world, "ranks_agree": sum_worlds == float(world) * world, "version": info.get("rccl_version"),
+            "library": info.get("library"), "backend_used": "rccl" if rccl_used else backend}
+
+
+def dry_run(args, D, R, rank, world, paths_per_launch, scaling):
+    """The control plane and the line's N-rank fields without a GPU: every rank contributes made-up counters (rank r:
+    1000 (r + 1) rays per path-thousand, 2 ms of exchange per step) through D.aggregate exactly like a real run."""
+    D.init_control_plane(rank, world)
+    paths = float(paths_per_launch * args.launches_per_step * args.steps)
+    rays = paths * (3.0 + rank)
+    elapsed, (total_rays, total_paths) = D.aggregate(1.0 + 0.25 * rank, [rays, paths])
+    exchange_ms, (sum_worlds, sum_exchanges, _) = D.aggregate(2.0 + rank, [world, args.steps, 0.0])
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mrays/sec on built-in scene at 1920x1080", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "none (dry run of the control plane: no GPU work, made-up counters)",
+            "config": {"workload": "dry run", "paths_per_launch": paths_per_launch, "total_paths_per_step": paths_per_launch * args.launches_per_step * world,
+                       "dist_backend": "gloo (dry run)",
+                       "rccl": rccl_report(world, False, {"rccl_version": 0, "library": None}, sum_worlds, "gloo (dry run)")},
+            "mpaths_per_s": total_paths / elapsed / 1e6,
+            "exchange": {"ms_per_step": exchange_ms, "per_step": sum_exchanges / world / args.steps, "share_of_step": exchange_ms / (elapsed / args.steps * 1e3)}}), flush=True)
+    if world > 1:
+        D.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +347,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configs (config.others)")
+    ap.add_argument("--total-paths", type=int, default=0,
+                    help="strong scaling (SURVEY 8e): the paths of ONE STEP for the whole job, split evenly over the ranks "
+                         "(rounded down to launches-per-step x 64 per rank); default 0 = weak scaling, the per-GPU work is fixed")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: every rank reports made-up counters through the same control plane and line assembly "
+                         "(tests/test_distributed_gloo.py runs this with two CPU ranks)")
     ap.add_argument("--dist-backend", default="rccl", choices=["rccl", "gloo"],
                     help="rccl = the library's ncclReduce over xGMI, one rank per GPU (default); gloo = the same sum staged "
                          "through host memory, ranks may share a GPU -- for exercising the N > 1 path on a 1-GPU box")
@@ -273,6 +371,15 @@ def main():
         import torch  # noqa: F401  control plane only; imported before the library so that one HIP/RCCL copy is shared
     import robigo_luculenta_amd as R
 
+    paths_per_launch = args.batches_per_launch * BATCH
+    scaling = "weak"
+    if args.total_paths:
+        scaling = "strong"
+        paths_per_launch = args.total_paths // world // args.launches_per_step // 64 * 64
+        if paths_per_launch == 0:
+            raise SystemExit("bench.py: --total-paths %d is less than 64 paths per launch and rank" % args.total_paths)
+    if args.dry_run:
+        return dry_run(args, D, R, rank, world, paths_per_launch, scaling)
     if R.device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     D.init_control_plane(rank, world)
@@ -310,8 +417,8 @@ def main():
     trace.set_fetch(R.FETCH_LDS if args.fetch == "lds" else R.FETCH_GLOBAL)
     plot = R.PlotUnit(rank, W, H, device=device)
     gather = R.GatherUnit(W, H, device=device) if rank == 0 else None
-    paths_per_launch = args.batches_per_launch * BATCH
     next_path = [0]
+    host_exchange = [0.0, 0]   # the host-staged fallback: seconds and count of the gloo sums
 
     def gather_step():
         """Task::Gather on `world` ranks (app.rs:143-148)."""
@@ -319,7 +426,11 @@ def main():
             R.gather_allreduce(gather, plot, comm)   # rl_gather_unit_allreduce: ncclReduce onto rank 0, Kahan there, clear elsewhere
         elif world > 1:   # host-staged: download, gloo sum, upload on the root
             host = plot.tristimulus_buffer
-            if D.host_staged_reduce(host, root=0):
+            t_ex = time.perf_counter()
+            holds_sum = D.host_staged_reduce(host, root=0)
+            host_exchange[0] += time.perf_counter() - t_ex
+            host_exchange[1] += 1
+            if holds_sum:
                 plot.upload(host)
                 gather.accumulate(plot)
             else:
@@ -348,6 +459,8 @@ def main():
         gather_step()  # build the communicator's rings outside the timed region (RCCL connects lazily)
     fence()
     p0, s0, ms0 = trace.stats()
+    ex_n0, ex_ms0 = plot.exchange_stats() if comm is not None else (0, 0.0)
+    hx0 = list(host_exchange)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -356,6 +469,16 @@ def main():
     p1, s1, ms1 = trace.stats()
     rays, paths, kernel_ms = s1 - s0, p1 - p0, ms1 - ms0
     elapsed, (total_rays, total_paths) = D.aggregate(t1 - t0, [rays, paths])
+    # the exchange, per step: device time of the ncclReduce calls on this rank's plot stream (rl_plot_unit_exchange_stats),
+    # or host time of the staged sums; MAX over ranks (a collective ends when its slowest rank does)
+    if comm is not None:
+        ex_n1, ex_ms1 = plot.exchange_stats()
+        my_exchange_ms, my_exchanges = (ex_ms1 - ex_ms0) / args.steps, ex_n1 - ex_n0
+        info = comm.info()
+    else:
+        my_exchange_ms, my_exchanges = (host_exchange[0] - hx0[0]) * 1e3 / args.steps, host_exchange[1] - hx0[1]
+        info = {"world": world, "rccl_version": 0, "library": None}
+    exchange_ms, (sum_worlds, sum_exchanges, sum_kernel_ms) = D.aggregate(my_exchange_ms, [info["world"], my_exchanges, kernel_ms])
 
     if rank == 0:
         f_seg = flops_per_ray(objs)
@@ -363,7 +486,7 @@ def main():
         launch_ms = kernel_ms / n_launches            # HIP events on the trace unit's own stream (rl_api.hip)
         rays_per_launch = rays / n_launches
         achieved = rays_per_launch * f_seg / (launch_ms * 1e-3) / 1e12
-        ex = executed_from_profile(R, args.config, args.fetch, rays_per_launch, launch_ms)
+        ex = executed_from_profile(R, args.config, args.fetch, rays_per_launch, launch_ms, paths_per_launch)
         executed, traffic = ex if isinstance(ex, tuple) else (ex, None)
         out = {
             "metric": "Mrays/sec on built-in scene at %dx%d" % (W, H),
@@ -371,7 +494,7 @@ def main():
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "built-in %s scene (%d objects), %dx%d, fused trace+plot; one step = %d launches of %d batches of "
                                    "524288 paths per GPU, then the gather (%s); RNG stream = rank, primitives in %s"
@@ -382,16 +505,27 @@ def main():
                                       "LDS" if args.fetch == "lds" else "global/scalar cache"),
                        "config": args.config, "paths_per_step_per_gpu": paths_per_launch * args.launches_per_step,
                        "paths_per_launch": paths_per_launch, "seed": args.seed, "build_id": R.build_id(),
-                       "dist_backend": None if world == 1 else args.dist_backend},
+                       "total_paths_per_step": paths_per_launch * args.launches_per_step * world,
+                       "dist_backend": None if world == 1 else args.dist_backend,
+                       "rccl": None if world == 1 else rccl_report(world, comm is not None, info, sum_worlds, args.dist_backend)},
             "mpaths_per_s": total_paths / elapsed / 1e6,
             "batches_per_s": total_paths / elapsed / BATCH,
             "segments_per_path": total_rays / max(total_paths, 1.0),
             "timed_region_s": elapsed,
+            "exchange": None if world == 1 else {
+                "ms_per_step": exchange_ms, "per_step": sum_exchanges / world / args.steps, "bytes": 3 * W * H * 4,
+                "what": ("device time of ncclReduce (f32 sum of the %d-float XYZ buffer onto rank 0) between events on the plot unit's "
+                         "stream, max over ranks" % (3 * W * H)) if comm is not None else "host time of the gloo sum of the downloaded buffers, max over ranks",
+                "share_of_step": exchange_ms / (elapsed / args.steps * 1e3),
+                "kernel_share_of_step": (sum_kernel_ms / world) / (elapsed * 1e3)},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                         # what the hardware did, first (profiles/*_pmc.json of this build; None when that profile is stale):
+                         "frac_executed": executed.get("useful_lane_slots_vs_2cyc"),   # VALU lane-slots used / lane-slots at one wave64 instruction per 2 cycles per SIMD
+                         "valu_busy": executed.get("issue_frac_vs_2cyc"),              # VALU instructions issued / issue slots at that rate
                          "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
                          "frac_is": "ALGORITHMIC: the reference's linear-scan flops per ray (SURVEY 8d) x rays / kernel time, over the "
                                     "FP32-vector peak.  The kernel culls most of that scan, so this is a speed-up-over-linear-scan "
-                                    "figure, not a utilisation; `executed` below is what the hardware did",
+                                    "figure, not a utilisation; frac_executed / valu_busy (details in `executed`) are what the hardware did",
                          "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flops_per_ray": f_seg,
@@ -409,7 +543,7 @@ def main():
             workers = max(1, min(usable_cores(), 85))
             out["config"]["others"] += [measure_app(R, fused, workers, device) for fused in (False, True)]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(objs, cam, W, H)
+            out["cpu_baseline"] = cpu_baseline(R, objs, cam, W, H)
         print(json.dumps(out), flush=True)
     if world > 1:
         D.shutdown()

@@ -92,9 +92,11 @@ extern "C" {
     pub fn rl_comm_init_all(devices: *const c_int, n: c_int, out: *mut *mut RlComm) -> c_int;
     pub fn rl_comm_destroy(comm: *mut RlComm) -> c_int;
     pub fn rl_comm_rank(comm: *const RlComm, rank: *mut c_int, world: *mut c_int) -> c_int;
+    pub fn rl_comm_info(comm: *const RlComm, rank: *mut c_int, world: *mut c_int, rccl_version: *mut c_int, library_path: *mut c_char, path_cap: u32) -> c_int;
     pub fn rl_comm_group_start() -> c_int;
     pub fn rl_comm_group_end() -> c_int;
     pub fn rl_plot_unit_reduce(u: *mut RlPlotUnit, comm: *mut RlComm, root: c_int) -> c_int;
+    pub fn rl_plot_unit_exchange_stats(u: *mut RlPlotUnit, exchanges: *mut u64, device_ms: *mut f64) -> c_int;
     pub fn rl_plot_unit_add(dst: *mut RlPlotUnit, src: *mut RlPlotUnit) -> c_int;
     pub fn rl_gather_unit_allreduce(gather: *mut RlGatherUnit, plot: *mut RlPlotUnit, comm: *mut RlComm) -> c_int;
 

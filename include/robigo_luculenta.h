@@ -264,6 +264,10 @@ int rl_comm_init_rank(const uint8_t id[RL_COMM_ID_BYTES], int world, int rank, i
 int rl_comm_init_all(const int* devices, int n, RlComm** out);
 int rl_comm_destroy(RlComm* comm);
 int rl_comm_rank(const RlComm* comm, int* rank, int* world);
+/* What the exchange really runs on, for a measurement that has to explain itself: the rank, the size RCCL reports for the
+ * communicator (ncclCommCount), the RCCL version (ncclGetVersion, e.g. 22707) and the path of the library that was
+ * loaded.  Any output may be NULL. */
+int rl_comm_info(const RlComm* comm, int* rank, int* world, int* rccl_version, char* library_path, uint32_t path_cap);
 /* ncclGroupStart / ncclGroupEnd: a single host thread that issues the collective for several ranks brackets
  * the calls with these (one thread or process per rank needs neither). */
 int rl_comm_group_start(void);
@@ -272,6 +276,9 @@ int rl_comm_group_end(void);
  * buffer, in place (ncclReduce, f32, sum).  Collective: every rank calls it with its own plot unit of the same
  * size.  Queued on the plot unit's stream, i.e. after every plot / fused render into the buffer. */
 int rl_plot_unit_reduce(RlPlotUnit* unit, RlComm* comm, int root);
+/* Device time of this unit's exchanges so far: every rl_plot_unit_reduce is bracketed by events on the plot unit's
+ * stream.  Waits for the ones still in flight.  Cumulative since creation. */
+int rl_plot_unit_exchange_stats(RlPlotUnit* unit, uint64_t* exchanges, double* device_ms);
 /* dst += src for two plot units on the SAME device (two RNG streams rendered by one GPU); src is left as it is. */
 int rl_plot_unit_add(RlPlotUnit* dst, RlPlotUnit* src);
 /* Task::Gather on G GPUs in one call per rank: rl_plot_unit_reduce(plot, comm, 0), then on rank 0

@@ -178,6 +178,12 @@ class PlotUnit(_Handle):
         """The GatherUnit-time exchange: sum of every rank's buffer onto `root` (ncclReduce on the unit's stream)."""
         check(lib.rl_plot_unit_reduce(self._h, comm.handle, root))
 
+    def exchange_stats(self):
+        """(exchanges so far, device milliseconds they took): rl_plot_unit_exchange_stats."""
+        n, ms = C.c_uint64(0), C.c_double(0.0)
+        check(lib.rl_plot_unit_exchange_stats(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def add(self, other):
         """self += other (same device)."""
         check(lib.rl_plot_unit_add(self._h, other.handle))
@@ -259,6 +265,13 @@ class Comm(_Handle):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         check(lib.rl_comm_init_rank(buf, world, rank, device, C.byref(self._h)))
         self.world, self.rank, self.device = world, rank, device
+
+    def info(self):
+        """{rank, world (as RCCL counts the communicator), rccl_version, library}: rl_comm_info."""
+        rank, world, version = C.c_int(0), C.c_int(0), C.c_int(0)
+        path = C.create_string_buffer(512)
+        check(lib.rl_comm_info(self._h, C.byref(rank), C.byref(world), C.byref(version), path, 512))
+        return {"rank": rank.value, "world": world.value, "rccl_version": version.value, "library": path.value.decode()}
 
     @classmethod
     def init_all(cls, devices):

@@ -95,6 +95,7 @@ SIGNATURES = {
     "rl_plot_unit_clear": (_i, [_vp]),
     "rl_plot_unit_sync": (_i, [_vp]),
     "rl_plot_unit_reduce": (_i, [_vp, _vp, _i]),
+    "rl_plot_unit_exchange_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "rl_plot_unit_add": (_i, [_vp, _vp]),
     "rl_gather_unit_allreduce": (_i, [_vp, _vp, _vp]),
     "rl_comm_unique_id": (_i, [_vp]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "rl_comm_init_all": (_i, [C.POINTER(_i), _i, _pp]),
     "rl_comm_destroy": (_i, [_vp]),
     "rl_comm_rank": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "rl_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.c_char_p, _u32]),
     "rl_comm_group_start": (_i, []),
     "rl_comm_group_end": (_i, []),
     "rl_plot_unit_device_buffer": (_i, [_vp, _pp]),

@@ -141,6 +141,9 @@ struct RlPlotUnit {
     hipEvent_t ready;   // recorded on `stream` when a gather (or a reader on another stream) takes the buffer
     hipEvent_t cleared; // recorded on the gather stream after accumulate + clear
     hipEvent_t tail;    // scratch: recorded on `stream` by a fused launch that has to start behind everything queued there
+    std::vector<EventPair> exchanges; // around every rl_plot_unit_reduce on `stream`, not yet read (rl_plot_unit_exchange_stats)
+    uint64_t exchange_count = 0;
+    double exchange_ms = 0.0;
     Ticket ticket;      // rl_trace_unit_render_fused_begin: ended by whatever uses the buffer next (plot_settle)
 };
 
@@ -1035,6 +1038,7 @@ int rl_plot_unit_destroy(RlPlotUnit* u) {
     if (u->ready) (void)hipEventDestroy(u->ready);
     if (u->cleared) (void)hipEventDestroy(u->cleared);
     if (u->tail) (void)hipEventDestroy(u->tail);
+    for (EventPair& ep : u->exchanges) (void)hipEventDestroy(ep.start), (void)hipEventDestroy(ep.stop);
     if (u->owns && u->xyz) (void)hipFree(u->xyz);
     if (u->cie) (void)hipFree(u->cie);
     delete u;
@@ -1330,7 +1334,9 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    std::string error;
+    decltype(&ncclGetVersion) GetVersion = nullptr; // optional
+    decltype(&ncclCommCount) CommCount = nullptr;   // optional: what the communicator itself says its size is
+    std::string error, path;
 };
 
 RcclApi* rccl_api() {
@@ -1357,7 +1363,10 @@ RcclApi* rccl_api() {
         names.push_back("/opt/rocm/lib/librccl.so.1");
         for (const std::string& n : names) {
             api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-            if (api.handle) break;
+            if (api.handle) {
+                api.path = n;
+                break;
+            }
         }
         if (!api.handle) {
             api.error = std::string("RCCL (librccl.so.1) could not be loaded: ") + dlerror();
@@ -1369,6 +1378,8 @@ RcclApi* rccl_api() {
         RL_BIND(GetUniqueId) RL_BIND(CommInitRank) RL_BIND(CommInitAll) RL_BIND(CommDestroy) RL_BIND(Reduce)
         RL_BIND(GroupStart) RL_BIND(GroupEnd) RL_BIND(GetErrorString)
 #undef RL_BIND
+        api.GetVersion = (decltype(api.GetVersion))dlsym(api.handle, "ncclGetVersion");
+        api.CommCount = (decltype(api.CommCount))dlsym(api.handle, "ncclCommCount");
     });
     return &api;
 }
@@ -1483,7 +1494,53 @@ int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
     if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     const size_t count = (size_t)u->width * u->height * 3;
     // In place on the root; on the plot unit's stream, i.e. after every plot / fused splat into this buffer.
+    EventPair ep;
+    RL_HIP(hipEventCreate(&ep.start));
+    RL_HIP(hipEventCreate(&ep.stop));
+    RL_HIP(hipEventRecord(ep.start, u->stream));
     RL_NCCL(api, api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream));
+    RL_HIP(hipEventRecord(ep.stop, u->stream));
+    u->exchanges.push_back(ep);
+    return RL_OK;
+}
+
+int rl_plot_unit_exchange_stats(RlPlotUnit* u, uint64_t* exchanges, double* device_ms) {
+    if (!u) return fail(RL_E_INVALID, "null plot unit");
+    int rc = use_device(u->device);
+    if (rc != RL_OK) return rc;
+    for (EventPair& ep : u->exchanges) {
+        RL_HIP(hipEventSynchronize(ep.stop));
+        float ms = 0.0f;
+        RL_HIP(hipEventElapsedTime(&ms, ep.start, ep.stop));
+        u->exchange_ms += (double)ms;
+        u->exchange_count += 1;
+        (void)hipEventDestroy(ep.start);
+        (void)hipEventDestroy(ep.stop);
+    }
+    u->exchanges.clear();
+    if (exchanges) *exchanges = u->exchange_count;
+    if (device_ms) *device_ms = u->exchange_ms;
+    return RL_OK;
+}
+
+int rl_comm_info(const RlComm* c, int* rank, int* world, int* rccl_version, char* library_path, uint32_t path_cap) {
+    if (!c) return fail(RL_E_INVALID, "null communicator");
+    RcclApi* api = rccl_api();
+    if (!api->error.empty()) return fail(RL_E_NO_DEVICE, api->error);
+    if (rank) *rank = c->rank;
+    if (world) { // the communicator's own count where RCCL exports it: "did RCCL see N ranks" answered by RCCL
+        int n = c->world;
+        if (api->CommCount) RL_NCCL(api, api->CommCount((ncclComm_t)c->nccl, &n));
+        *world = n;
+    }
+    if (rccl_version) {
+        int v = 0;
+        if (api->GetVersion) RL_NCCL(api, api->GetVersion(&v));
+        *rccl_version = v;
+    }
+    if (library_path && path_cap) {
+        std::snprintf(library_path, path_cap, "%s", api->path.c_str());
+    }
     return RL_OK;
 }
 

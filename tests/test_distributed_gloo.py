@@ -75,3 +75,30 @@ def test_two_rank_gloo_exchange_matches_sum_of_streams(tmp_path):
     assert parts[0].any() and parts[1].any() and not np.array_equal(parts[0], parts[1])
     # disjoint RNG streams: two independent estimates of the same image
     assert abs(parts[0].sum() / parts[1].sum() - 1.0) < 0.25
+
+
+def test_the_n_rank_bench_line_says_what_the_exchange_ran_on_and_what_it_cost():
+    """a SCALE record must answer "did RCCL see N ranks" and "where did the time go" by itself.  bench.py's
+    --dry-run sends made-up counters of two CPU ranks through the control plane and line assembly of a real run:
+    value = SUM of the ranks' rays / MAX of their times, config.rccl = what every rank's communicator reports,
+    exchange.ms_per_step = MAX over ranks, and --total-paths turns the line into a strong-scaling one."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--launches-per-step", "2", "--total-paths", str(2 * 2 * 64 * 1000)],
+                         capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    assert run.returncode == 0, run.stderr.decode()[-2000:]
+    line = json.loads([l for l in run.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "Mrays/s"
+    assert line["config"]["total_paths_per_step"] == 2 * 2 * 64 * 1000 and line["config"]["paths_per_launch"] == 64 * 1000
+    paths = 64 * 1000 * 2 * 3                                    # per rank over the 3 steps
+    assert line["value"] == pytest.approx(paths * (3.0 + 4.0) / 1.25 / 1e6)   # rank r: (3 + r) rays per path, 1 + r / 4 seconds
+    rccl = line["config"]["rccl"]
+    assert rccl["world"] == 2 and rccl["ranks_agree"] is True and "backend_used" in rccl and "version" in rccl
+    ex = line["exchange"]
+    assert ex["ms_per_step"] == 3.0 and ex["per_step"] == 1.0 and 0 < ex["share_of_step"] < 1   # rank r: 2 + r ms
+    weak = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    line = json.loads([l for l in weak.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["config"]["paths_per_launch"] == 256 * 524288

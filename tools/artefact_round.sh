@@ -6,7 +6,7 @@
 #   with two ranks sharing the GPU, the VALU microbenchmark.  ~8 minutes.
 # Usage (through gpurun): bash tools/artefact_round.sh r02   -> then tools/install_artefacts.sh r02 here.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_console.txt 2>&1
