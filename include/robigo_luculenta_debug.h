@@ -12,7 +12,8 @@ extern "C" {
  * g++ builds agree bit-for-bit.  fn: 0 sin, 1 cos, 2 tan, 3 exp, 4 ln, 5 acos, 6 SF10 index of refraction
  * (material.rs:203-213), 7 sqrt, 8 x[i] / x[i+1 mod n], 9 x^(1/2.4) (srgb.rs:24), 10 the Russian-roulette
  * decision (trace_unit.rs:122-125) for the triples (x[i], x[m+i], x[2m+i]) = (rand, continue_chance,
- * intensity), i < m = n / 3, result 1 or 0 in y[i]. */
+ * intensity), i < m = n / 3, result 1 or 0 in y[i], 11 vector3.rs:56-67 normalise of the triples (x[i], x[m+i], x[2m+i])
+ * into (y[i], y[m+i], y[2m+i]). */
 int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
 /* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
  * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */

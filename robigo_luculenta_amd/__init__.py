@@ -393,7 +393,7 @@ def batch_histogram(device=0):
 
 def math_probe(fn, x, device=0):
     """Evaluates csrc/rl_math.h function `fn` on the GPU (diagnostics for the parity tests)."""
-    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10}
+    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10, "normalise": 11}
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.zeros_like(x)
     check(lib.rl_debug_math_probe(device, names[fn], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))

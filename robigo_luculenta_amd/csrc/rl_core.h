@@ -42,6 +42,33 @@ RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                           
 }
 RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
     const float m = sqrtf(rl_dot(v, v));
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Three IEEE divisions by the same m.  The compiler's division is v_div_scale x 2, v_rcp, a refinement of the
+    // reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup (11 instructions, 33 for a vector).
+    // Everything that depends on the divisor alone is shared here, and the scaling / fix-up steps are left out where
+    // they do nothing: v_div_scale passes its operands through and v_div_fixup its quotient when the divisor is a normal
+    // number far from the ends of the range and the numerator is zero or not tiny against it (the conditions below,
+    // from the instruction's definition).  What remains is the very same sequence of correctly rounded operations --
+    // rcp, e = fma(-m, y, 1), y = fma(e, y, y), q = x y, r = fma(-m, q, x), q = fma(r, y, q), r = fma(-m, q, x),
+    // q = fma(r, y, q) -- so the quotients are the compiler's bit for bit (the parity tests compare them with the g++
+    // build's divisions); a zero keeps its sign.  Any other operand in the wave: the plain divisions below.
+    const uint32_t bx = rl_f2u(v.x) & 0x7fffffffu, by = rl_f2u(v.y) & 0x7fffffffu, bz = rl_f2u(v.z) & 0x7fffffffu;
+    uint32_t least = bx - 1u < by - 1u ? bx - 1u : by - 1u; // (0 - 1 wraps to the largest value: zeros pass)
+    least = bz - 1u < least ? bz - 1u : least;
+    const bool plain = least >= 0x1f800000u - 1u                         // every component is 0 or at least 2^-64
+                       && rl_f2u(m) - 0x21800000u < 0x5d800000u - 0x21800000u; // 2^-60 <= m < 2^60 (NaN and 0 fail)
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+        float y = __builtin_amdgcn_rcpf(m);
+        y = __builtin_fmaf(__builtin_fmaf(-m, y, 1.0f), y, y);
+        auto quotient = [&](float x) {
+            float q = x * y;
+            q = __builtin_fmaf(__builtin_fmaf(-m, q, x), y, q);
+            q = __builtin_fmaf(__builtin_fmaf(-m, q, x), y, q);
+            return rl_u2f((rl_f2u(q) & 0x7fffffffu) | (rl_f2u(x) & 0x80000000u)); // m > 0: the quotient has x's sign, a zero too
+        };
+        return rl_f3(quotient(v.x), quotient(v.y), quotient(v.z));
+    }
+#endif
     const RlF3 u = rl_f3(v.x / m, v.y / m, v.z / m); // inf/NaN for m == 0, discarded below
     return (m == 0.0f) ? v : u;
 }

@@ -1272,12 +1272,19 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __res
 // Evaluates rl_math.h on the device so tests can compare it bit-for-bit with the host build.
 // fn: 0 sin 1 cos 2 tan 3 exp 4 log 5 acos 6 sf10 ior 7 sqrt 8 a/b (y = x[i] / x[i+1 mod n]) 9 powf(x, 1/2.4)
 // 10: rl_roulette_ends(unit = x[i], continue_chance = x[m + i], intensity = x[2m + i]) for i < m = n / 3 (1 or 0)
+// 11: rl_normalise((x[i], x[m + i], x[2m + i])) -> (y[i], y[m + i], y[2m + i])
 __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float* __restrict__ y, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (fn == 10) { // whole waves take part: the fast path is a wave-uniform decision
         const uint32_t m = n / 3, j = i < m ? i : 0;
         const bool ends = rl_roulette_ends(x[j], x[m + j], x[2 * m + j]);
         if (i < m) y[i] = ends ? 1.0f : 0.0f;
+        return;
+    }
+    if (fn == 11) { // rl_normalise of (x[i], x[m + i], x[2m + i]); whole waves take part: its shortcut is a wave-uniform decision
+        const uint32_t m = n / 3, j = i < m ? i : 0;
+        const RlF3 u = rl_normalise(rl_f3(x[j], x[m + j], x[2 * m + j]));
+        if (i < m) y[i] = u.x, y[m + i] = u.y, y[2 * m + i] = u.z;
         return;
     }
     if (i >= n) return;

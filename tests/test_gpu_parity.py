@@ -79,6 +79,40 @@ def test_ieee_sqrt_div_and_f64_islands_on_device():
     assert R.math_probe("gamma", g).tobytes() == wantg.tobytes()
 
 
+def test_normalise_with_the_shared_reciprocal_is_the_ieee_division_bit_for_bit():
+    """rl_normalise (vector3.rs:56-67) divides three components by one length; on the device the reciprocal's refinement is
+    shared and the scaling / fix-up steps of the compiler's division are skipped where they pass their operands through
+    (rl_core.h).  Against numpy's correctly rounded sqrt and division: ordinary vectors (the shortcut), vectors with zero,
+    negative-zero, tiny and huge components, zero and non-finite vectors (waves that fall back to the plain divisions)."""
+    rng = np.random.default_rng(12)
+
+    def ref(v):
+        v = v.astype(np.float32)
+        m = np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]).astype(np.float32)   # rl_dot's order
+        with np.errstate(all="ignore"):
+            u = (v / m).astype(np.float32)
+        return np.where(m == 0, v, u)
+
+    def check(v):
+        got = R.math_probe("normalise", v.reshape(-1)).reshape(3, -1)
+        want = ref(v)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (v[:, ~same.all(0)][:, :4], got[:, ~same.all(0)][:, :4], want[:, ~same.all(0)][:, :4])
+
+    n = 1 << 20
+    check(rng.normal(0, 1, (3, n)).astype(np.float32))                                          # directions
+    check((rng.normal(0, 1, (3, n)) * np.exp(rng.uniform(-40, 40, n))).astype(np.float32))      # any length the shortcut takes
+    v = rng.normal(0, 1, (3, n)).astype(np.float32)
+    v[rng.integers(0, 3, n), np.arange(n)] = 0.0                                                # axis-aligned normals: exact zeros
+    v[rng.integers(0, 3, n), np.arange(n)] *= np.float32(-1.0)                                  # ... of either sign
+    check(v)
+    edge = (rng.normal(0, 1, (3, n)) * np.exp(rng.uniform(-100, 88, (3, n)))).astype(np.float32)  # components tiny against the length,
+    edge[:, ::7] = 0.0                                                                            # lengths beyond 2^60, zero vectors
+    edge[0, ::11] = np.float32(1e-42)                                                             # denormal components
+    edge[1, ::13] = np.inf
+    check(edge)
+
+
 @pytest.mark.parametrize("fetch", [R.FETCH_LDS, R.FETCH_GLOBAL])
 def test_trace_photons_bit_exact_demo(demo, fetch):
     objs, cam, scene, oscene = demo
