@@ -617,8 +617,46 @@ RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) 
 // RL_PATH_ENDED_ON_EMITTER: the path hit emitter *emitter; its contribution is
 // rl_emission(sv, p->intensity, p->wavelength, *emitter), left to the caller so that the kernel can
 // evaluate the f64 Planck term for 64 ended paths at once instead of under divergence.
+// rl_acosf(a0), rl_acosf(a1) for the lanes with `wanted`.  On the GPU: called by every lane of a branch (whatever set of
+// lanes that is); the 2n arguments of the n wanting lanes are handed, through 128 floats of per-wave LDS scratch, to the
+// first 2n lanes of the branch, evaluated in one pass and handed back.  More arguments than lanes: one pass each.
+RL_HD void rl_acos_pair(bool wanted, float a0, float a1, float* scratch, float* r0, float* r1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) float LdsF32;
+    LdsF32* slots = (LdsF32*)scratch;
+    const uint64_t here = __builtin_amdgcn_ballot_w64(true), want = __builtin_amdgcn_ballot_w64(wanted);
+    const uint32_t n = (uint32_t)__popcll(want);
+    *r0 = *r1 = 0.0f;
+    if (n == 0) return;
+    if (2u * n <= (uint32_t)__popcll(here)) {
+        const uint32_t mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+        if (wanted) {
+            slots[rank] = a0;
+            slots[n + rank] = a1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float r = rl_acosf(mine < 2u * n ? slots[mine] : 0.0f);
+        if (mine < 2u * n) slots[64 + mine] = r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (wanted) {
+            *r0 = slots[64 + rank];
+            *r1 = slots[64 + n + rank];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
+#endif
+    *r0 = wanted ? rl_acosf(a0) : 0.0f;
+    *r1 = wanted ? rl_acosf(a1) : 0.0f;
+}
+
+// pair_scratch: 128 floats of per-wave LDS that nothing else uses during the bounce (GPU); unused on the host.
 RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint64_t path_index, RlPath* p,
-                    const RlHit& hit, float* value, uint32_t* emitter) {
+                    const RlHit& hit, float* value, uint32_t* emitter, float* pair_scratch = nullptr) {
     *value = 0.0f;
     if (hit.obj == RL_HIT_NONE) return RL_PATH_ENDED; // The Void
     const RlF4 oa = sv.objects[2 * hit.obj];
@@ -672,14 +710,22 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         if (soap) axis = surface_kind == RL_SURFACE_SPHERE ? rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal) : rl_f3(0.0f, 0.0f, 0.0f);
         const RlF3 unit_axis = rl_normalise(axis);
         float angle;
+        float cos_phi = 0.0f, cos_theta = 0.0f;
         if (soap) { // material.rs:267-305
             const float cos_alpha = rl_dot(in_dir, is.normal);
             if (rl_get_unit(rb.w[0]) - 0.3f > fabsf(cos_alpha)) new_dir = mirrored;
             else new_dir = in_dir;
+            cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
+            cos_theta = rl_clamp999(rl_dot(new_dir, unit_axis)); // Intersection.tangent
+        }
+        // The film's two arc cosines (material.rs:293-294): ~17 % of a wave's lanes need them, two each, at ~55 instructions
+        // of f64 arithmetic apiece -- the GPU evaluates both arguments of every film lane in ONE pass over the lanes that
+        // are enabled here (rl_acos_pair: everything that is not glass), the same function of the same arguments.
+        float acos_phi, acos_theta;
+        rl_acos_pair(soap, cos_phi, cos_theta, pair_scratch, &acos_phi, &acos_theta);
+        if (soap) {
             const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
-            const float cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
-            const float cos_theta = rl_clamp999(rl_dot(new_dir, unit_axis)); // Intersection.tangent
-            angle = phase_shift - rl_acosf(cos_phi) * 3.0f - rl_acosf(cos_theta) * 2.0f + RL_PI_F * 0.5f;
+            angle = phase_shift - acos_phi * 3.0f - acos_theta * 2.0f + RL_PI_F * 0.5f;
         } else {
             angle = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58
         }

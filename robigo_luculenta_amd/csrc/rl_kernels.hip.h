@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             segments += 1;
             float value;
             uint32_t emitter = 0;
-            const int status = rl_bounce(sv, job.seed, job.stream, my_path, &p, hit, &value, &emitter);
+            const int status = rl_bounce(sv, job.seed, job.stream, my_path, &p, hit, &value, &emitter, (float*)ws->ring_b); // (ring B is empty between scans)
             if (status != RL_PATH_CONTINUES) {
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
