@@ -9,6 +9,7 @@ cp $SRC/app_overlap.txt profiles/${TAG}_app_overlap.txt
 cp $SRC/bench.json profiles/${TAG}_bench.json
 cp $SRC/${TAG}_pmc.json profiles/${TAG}_pmc.json
 cp $SRC/${TAG}_pmc_summary.txt profiles/${TAG}_pmc_summary.txt
+cp $SRC/${TAG}_*_pmc.json profiles/ 2>/dev/null || true   # the other BASELINE configs (profile_round.sh)
 cp $SRC/image_parity.txt profiles/${TAG}_image_parity.txt
 cp $SRC/kernel_stats.txt profiles/${TAG}_kernel_event_stats.txt
 cp $SRC/app.txt profiles/${TAG}_app.txt
@@ -21,8 +22,9 @@ import json, sys
 tag = sys.argv[1]
 d = json.load(open("profiles/%s_bench.json" % tag))
 e = d["roofline"]["executed"]
+print("frac_executed", d["roofline"].get("frac_executed"), "valu_busy", d["roofline"].get("valu_busy"))
 print("Mrays/s %.1f  Mpaths/s %.1f  batches/s %.0f  ms/step %.2f  algorithmic frac %.3f  cpu %.2f Mrays/s (%d cores)"
       % (d["value"], d["mpaths_per_s"], d["batches_per_s"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"]))
 print("executed:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()})
-print("others:", [(o["config"], round(o["value"])) for o in d["config"]["others"]])
+print("others:", [(o["config"], round(o["value"]), (o.get("executed") or {}).get("active_lanes")) for o in d["config"]["others"]])
 PY
