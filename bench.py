@@ -391,8 +391,12 @@ def main():
         # get there (no GPU of its own, RCCL not loadable) would leave the others waiting inside it for ever, so the
         # ranks first agree that all of them can.
         failed = 0.0
-        if local_rank >= R.device_count():
-            exchange_note, failed = "rank %d has no GPU of its own (%d visible): RCCL admits one rank per device" % (rank, R.device_count()), 1.0
+        # one GPU per rank?  Decided by what the ranks' devices ARE (PCI bus ids), not by their numbers: a launcher may leave
+        # all GPUs visible to every rank (device = local rank) or hand each rank a mask of its own (device 0 everywhere)
+        mine = D.pick_device(local_rank, R.device_count())
+        ids = D.all_gather_strings(socket.gethostname()[:24] + "/" + R.device_pci_bus_id(mine))
+        if not D.one_gpu_per_rank(ids):
+            exchange_note, failed = "ranks share a GPU (%s): RCCL admits one rank per device" % ", ".join(ids), 1.0
         elif rank == 0:   # (the other ranks load the same library on the same node)
             try:
                 R.Comm.unique_id()   # loads RCCL; the id itself is not used
@@ -401,7 +405,7 @@ def main():
         _, (n_failed,) = D.aggregate(0.0, [failed])
         if not n_failed:
             try:
-                comm = D.make_comm(R, rank, world, local_rank)
+                comm = D.make_comm(R, rank, world, D.pick_device(local_rank, R.device_count()))
             except Exception as e:  # noqa: BLE001
                 exchange_note, failed = "rl_comm_init_rank failed on rank %d: %s" % (rank, e), 1.0
             _, (n_failed,) = D.aggregate(0.0, [failed])
@@ -409,7 +413,7 @@ def main():
             comm = None
             exchange_note = exchange_note or "the communicator did not come up on another rank"
             args.dist_backend = "gloo (fallback: %s)" % exchange_note
-    device = local_rank if comm is not None or world == 1 else local_rank % R.device_count()
+    device = D.pick_device(local_rank, R.device_count())
 
     objs, cam, W, H, label = scene_of(R, args.config)
     scene = R.Scene(objs, cam, device=device)

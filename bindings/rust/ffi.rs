@@ -42,6 +42,7 @@ pub enum RlScheduler {} pub enum RlComm {}
 extern "C" {
     pub fn rl_last_error() -> *const c_char;
     pub fn rl_device_count() -> c_int;
+    pub fn rl_device_pci_bus_id(device: c_int, out: *mut c_char, cap: u32) -> c_int;
     pub fn rl_version() -> *const c_char;
     pub fn rl_build_id() -> *const c_char;
     pub fn rl_scene_builtin_desc(which: c_int, param: c_int, objects: *mut RlObjectDesc, cap: u32,

@@ -118,6 +118,9 @@ typedef struct RlComm RlComm;
 const char* rl_last_error(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int rl_device_count(void);
+/* The PCI bus id ("0000:c1:00.0") of visible device `device`: what tells two processes whether "device 0" is the same GPU
+ * for both (ranks launched with a per-rank device mask) or not -- RCCL admits one rank per GPU. */
+int rl_device_pci_bus_id(int device, char* out, uint32_t cap);
 const char* rl_version(void);
 /* 16 hex digits: a hash of the sources this library's device code was compiled from (csrc/Makefile).  Profiles
  * record it so that counter-derived figures are never quoted for a different build. */

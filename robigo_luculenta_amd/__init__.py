@@ -21,6 +21,13 @@ FETCH_LDS, FETCH_GLOBAL = 0, 1
 TASK_SLEEP, TASK_TRACE, TASK_PLOT, TASK_GATHER, TASK_TONEMAP = range(5)
 
 
+def device_pci_bus_id(device=0):
+    """PCI bus id of a visible device (rl_device_pci_bus_id)."""
+    buf = C.create_string_buffer(64)
+    check(lib.rl_device_pci_bus_id(device, buf, 64))
+    return buf.value.decode()
+
+
 def device_count():
     return lib.rl_device_count()
 

@@ -69,6 +69,7 @@ _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "rl_last_error": (C.c_char_p, []),
     "rl_device_count": (_i, []),
+    "rl_device_pci_bus_id": (_i, [_i, C.c_char_p, _u32]),
     "rl_version": (C.c_char_p, []),
     "rl_build_id": (C.c_char_p, []),
     "rl_scene_builtin_desc": (_i, [_i, _i, _vp, _u32, C.POINTER(_u32), C.POINTER(RlCameraDesc)]),

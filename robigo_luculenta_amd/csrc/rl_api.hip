@@ -297,7 +297,15 @@ int rl_device_count(void) {
     return n;
 }
 
-const char* rl_version(void) { return "robigo-luculenta_amd 0.2 (gfx950)"; }
+int rl_device_pci_bus_id(int device, char* out, uint32_t cap) {
+    if (!out || cap < 16) return fail(RL_E_INVALID, "output buffer too small for a PCI bus id");
+    const int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    RL_HIP(hipDeviceGetPCIBusId(out, (int)cap, device));
+    return RL_OK;
+}
+
+const char* rl_version(void) { return "robigo-luculenta_amd 0.3 (gfx950)"; }
 
 #ifndef RL_BUILD_ID
 #define RL_BUILD_ID "unknown"

@@ -96,3 +96,28 @@ def make_comm(R, rank, world, device):
     if payload[0] != 1:
         raise error if error is not None else RuntimeError("rank 0 could not create an RCCL communicator id")
     return R.Comm(payload[1:], world, rank, device)
+
+
+def all_gather_strings(text, max_bytes=64):
+    """Every rank's `text` (one short string each), in rank order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [text]
+    raw = text.encode()[:max_bytes]
+    mine = torch.zeros(max_bytes, dtype=torch.uint8)
+    mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    parts = [torch.zeros(max_bytes, dtype=torch.uint8) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [bytes(p.numpy().tobytes()).rstrip(b"\0").decode() for p in parts]
+
+
+def pick_device(local_rank, n_visible):
+    """The visible device a rank uses: its local rank where the launcher leaves every GPU visible, device
+    (local_rank mod n) where it hands every rank a mask of its own (then n is usually 1)."""
+    return local_rank if local_rank < n_visible else local_rank % max(n_visible, 1)
+
+
+def one_gpu_per_rank(bus_ids):
+    """RCCL admits one rank per GPU: true iff the ranks' (host, PCI bus id) pairs are all different."""
+    return len(set(bus_ids)) == len(bus_ids)

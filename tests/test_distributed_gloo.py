@@ -46,6 +46,10 @@ def _worker(rank, world, port, out_dir):
     # the 128-byte communicator id travels from rank 0 to everybody (rl_comm_unique_id -> rl_comm_init_rank)
     uid = bytes(range(128)) if rank == 0 else None
     assert D.broadcast_bytes(uid, 128, root=0) == bytes(range(128))
+    # which GPU is whose: the ranks compare what their devices ARE (host / PCI bus id), whatever their numbers are
+    assert D.all_gather_strings("host/0000:%02x:00.0" % (0xc1 + rank)) == ["host/0000:c1:00.0", "host/0000:c2:00.0"]
+    assert D.one_gpu_per_rank(["h/a", "h/b"]) and not D.one_gpu_per_rank(["h/a", "h/a"])
+    assert (D.pick_device(3, 8), D.pick_device(3, 1), D.pick_device(5, 4)) == (3, 0, 1)
     mine = _rank_buffer(rank)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), mine)
     summed = mine.copy()
