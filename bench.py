@@ -4,8 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: bench.py starts its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = `--launches-per-step` (8) fused TraceUnit::render + PlotUnit::plot launches of `--batches-per-launch`
-(256) batches of 524,288 camera paths each (trace_unit.rs:67) on the built-in demo scene (app.rs:166-363), then the
+One "step" = `--launches-per-step` (2) fused TraceUnit::render + PlotUnit::plot launches of `--batches-per-launch`
+(1024) batches of 524,288 camera paths each (trace_unit.rs:67) on the built-in demo scene (app.rs:166-363), then the
 GatherUnit step: with N > 1 the ranks' XYZ plot buffers are summed onto rank 0 by the library's own RCCL exchange
 (rl_plot_unit_reduce: one ncclReduce over xGMI), rank 0 Kahan-accumulates and every rank clears
 (gather_unit.rs:49-64, app.rs:147).  Every rank renders the full frame with its own RNG stream (stream = rank) --
@@ -341,8 +341,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="demo-1080p", choices=sorted(CONFIGS))
-    ap.add_argument("--launches-per-step", type=int, default=8)
-    ap.add_argument("--batches-per-launch", type=int, default=256)
+    ap.add_argument("--launches-per-step", type=int, default=2)
+    ap.add_argument("--batches-per-launch", type=int, default=1024)
     ap.add_argument("--fetch", default="lds", choices=["lds", "global"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -105,4 +105,4 @@ def test_the_n_rank_bench_line_says_what_the_exchange_ran_on_and_what_it_cost():
     weak = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--gpus", "2", "--steps", "1", "--warmup", "0"],
                           capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(_free_port())))
     line = json.loads([l for l in weak.stdout.decode().splitlines() if l.startswith("{")][-1])
-    assert line["scaling"] == "weak" and line["config"]["paths_per_launch"] == 256 * 524288
+    assert line["scaling"] == "weak" and line["config"]["paths_per_launch"] == 1024 * 524288
