@@ -141,7 +141,7 @@ struct RlPlotUnit {
     hipEvent_t ready;   // recorded on `stream` when a gather (or a reader on another stream) takes the buffer
     hipEvent_t cleared; // recorded on the gather stream after accumulate + clear
     hipEvent_t tail;    // scratch: recorded on `stream` by a fused launch that has to start behind everything queued there
-    std::vector<EventPair> exchanges; // around every rl_plot_unit_reduce on `stream`, not yet read (rl_plot_unit_exchange_stats)
+    std::vector<EventPair> exchanges, exchange_pool; // around every rl_plot_unit_reduce on `stream`, not yet read (rl_plot_unit_exchange_stats); spare pairs
     uint64_t exchange_count = 0;
     double exchange_ms = 0.0;
     Ticket ticket;      // rl_trace_unit_render_fused_begin: ended by whatever uses the buffer next (plot_settle)
@@ -1047,6 +1047,7 @@ int rl_plot_unit_destroy(RlPlotUnit* u) {
     if (u->cleared) (void)hipEventDestroy(u->cleared);
     if (u->tail) (void)hipEventDestroy(u->tail);
     for (EventPair& ep : u->exchanges) (void)hipEventDestroy(ep.start), (void)hipEventDestroy(ep.stop);
+    for (EventPair& ep : u->exchange_pool) (void)hipEventDestroy(ep.start), (void)hipEventDestroy(ep.stop);
     if (u->owns && u->xyz) (void)hipFree(u->xyz);
     if (u->cie) (void)hipFree(u->cie);
     delete u;
@@ -1491,6 +1492,24 @@ int rl_comm_group_end(void) {
     return RL_OK;
 }
 
+namespace {
+// Reads the `n` oldest exchange timings of `u` into its totals (waits for them) and returns their events to the pool.
+int exchanges_harvest(RlPlotUnit* u, size_t n) {
+    if (n > u->exchanges.size()) n = u->exchanges.size();
+    for (size_t i = 0; i < n; ++i) {
+        EventPair& ep = u->exchanges[i];
+        RL_HIP(hipEventSynchronize(ep.stop));
+        float ms = 0.0f;
+        RL_HIP(hipEventElapsedTime(&ms, ep.start, ep.stop));
+        u->exchange_ms += (double)ms;
+        u->exchange_count += 1;
+        u->exchange_pool.push_back(ep);
+    }
+    u->exchanges.erase(u->exchanges.begin(), u->exchanges.begin() + (long)n);
+    return RL_OK;
+}
+} // namespace
+
 int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
     if (!u || !comm) return fail(RL_E_INVALID, "null handle");
     if (comm->device != u->device) return fail(RL_E_STATE, "communicator rank and plot unit live on different devices");
@@ -1502,9 +1521,17 @@ int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
     if ((rc = plot_settle(u)) != RL_OK) return rc; // a fused render begun into this buffer ends first
     const size_t count = (size_t)u->width * u->height * 3;
     // In place on the root; on the plot unit's stream, i.e. after every plot / fused splat into this buffer.
+    // bracketed by events for rl_plot_unit_exchange_stats; a long run never asks, so the pairs are recycled and at most
+    // 32 stay unread (the oldest is complete long before: it is on this unit's stream, 32 exchanges back)
+    if (u->exchanges.size() >= 32 && (rc = exchanges_harvest(u, 16)) != RL_OK) return rc;
     EventPair ep;
-    RL_HIP(hipEventCreate(&ep.start));
-    RL_HIP(hipEventCreate(&ep.stop));
+    if (!u->exchange_pool.empty()) {
+        ep = u->exchange_pool.back();
+        u->exchange_pool.pop_back();
+    } else {
+        RL_HIP(hipEventCreate(&ep.start));
+        RL_HIP(hipEventCreate(&ep.stop));
+    }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     RL_NCCL(api, api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream));
     RL_HIP(hipEventRecord(ep.stop, u->stream));
@@ -1516,16 +1543,7 @@ int rl_plot_unit_exchange_stats(RlPlotUnit* u, uint64_t* exchanges, double* devi
     if (!u) return fail(RL_E_INVALID, "null plot unit");
     int rc = use_device(u->device);
     if (rc != RL_OK) return rc;
-    for (EventPair& ep : u->exchanges) {
-        RL_HIP(hipEventSynchronize(ep.stop));
-        float ms = 0.0f;
-        RL_HIP(hipEventElapsedTime(&ms, ep.start, ep.stop));
-        u->exchange_ms += (double)ms;
-        u->exchange_count += 1;
-        (void)hipEventDestroy(ep.start);
-        (void)hipEventDestroy(ep.stop);
-    }
-    u->exchanges.clear();
+    if ((rc = exchanges_harvest(u, u->exchanges.size())) != RL_OK) return rc;
     if (exchanges) *exchanges = u->exchange_count;
     if (device_ms) *device_ms = u->exchange_ms;
     return RL_OK;

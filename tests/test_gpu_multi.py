@@ -98,6 +98,17 @@ def test_rccl_exchange_through_the_c_abi_with_one_rank(R):
     assert g2.tristimulus_buffer.tobytes() == before.tobytes()
     with pytest.raises(R.RlError):
         R.Comm.init_all([0, 0])       # RCCL admits one rank per device
+    # what the exchange ran on and what it cost (bench.py's config.rccl / exchange): the communicator's own count, the
+    # RCCL version, the library that was loaded; every reduce timed on the plot stream, unread timings bounded
+    info = comm.info()
+    assert info["rank"] == 0 and info["world"] == 1 and info["rccl_version"] > 20000 and "rccl" in info["library"]
+    n0, ms0 = p.exchange_stats()
+    assert n0 == 3 and ms0 > 0.0      # reduce + two allreduces so far
+    for _ in range(70):               # more than the library keeps unread: the oldest are folded into the totals
+        p.reduce(comm, root=0)
+    n1, ms1 = p.exchange_stats()
+    assert n1 == 73 and ms1 > ms0 and (ms1 - ms0) / 70 < 5.0
+    assert len(R.device_pci_bus_id(0).split(":")) == 3
 
 
 @pytest.mark.parametrize("fused", [False, True])
