@@ -10,15 +10,15 @@
 //     exec mask into a per-wave LDS stash; a lane whose path ended pops the next ray from the stash,
 //     so the scan always runs with all lanes busy until the global work queue (one atomic per 256
 //     paths per wave) drains;
-//   * the scan (rl_scan_wave) runs only cheap exact reject tests lane-per-ray; every expensive tail
-//     (sphere roots, cluster members, prism CSG) is compacted with ballot/mbcnt into LDS rings and
+//   * the scan (rl_scan_wave) runs only cheap reject / cull tests lane-per-ray; every expensive tail
+//     (sphere roots, cluster members, prisms) is compacted with ballot/mbcnt into LDS rings and
 //     evaluated 64 (item, ray) pairs at a time, results min-merged per ray with ds_min_u64;
 //   * results leave either as MappedPhoton records (un-fused, bit-comparable with the CPU) or as
 //     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
 //     in fused mode the paths that ended on a light wait in a per-wave LDS queue until 64 of them can
 //     be evaluated (f64 Planck term) and splatted with a full exec mask;
-//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue (one instruction per 3.0
-//     cycles per SIMD, 90 % of what a plain multiply/add stream reaches at this occupancy);
+//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue at the kernel's instruction mix
+//     (one instruction per 3.3 cycles per SIMD: 70 % full-rate, 27 % half-rate, 1.4 % transcendental);
 //   * OPEN variant: the kernel stays resident and takes the paths of blocking render calls from a job table the host
 //     appends to while it runs (RlOpenDev / RlOpenCtl below); at most 120 VGPRs so that the small kernels of the other
 //     units run beside it.
@@ -231,7 +231,7 @@ __device__ __forceinline__ void rl_fetch_cull_ray(uint32_t owner, const RlCullRa
     r.len = 0.0f;
 }
 
-// Per-wave LDS scratch of the scan: the merge keys and two rings of deferred work.
+// Per-wave LDS scratch of the scan: the merge keys and three rings of deferred work.
 struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
@@ -265,11 +265,13 @@ struct RlOpenWg {
 // lane, with the ray fetched across lanes (ds_bpermute):
 //   * direct spheres: reject = sign bits of the discriminant q and of d.co (16 flops + 3 int ops,
 //     geometry.rs:204-216 in the scaled form of rl_core.h) -> ring B;
-//   * sphere clusters (rl_scene.h): reject = conservative bounding-sphere test -> ring A; a ring-A
-//     round runs the same reject test of the cluster's RL_CLUSTER_K members -> ring B;
+//   * sphere clusters (rl_scene.h): group bounds (wave-uniform) -> ring S; a ring-S round tests the group's cluster
+//     bounds -> ring A; a ring-A round tests the cluster's RL_CLUSTER_K members, all with the conservative cull test
+//     (rl_cull_pass: far bound included) -> ring B;
 //   * ring B rounds: exact IEEE sqrt / root selection (geometry.rs:217-240), then min-merge;
-//   * hexagonal prisms (~600 instructions per test): conservative bounding-sphere test -> ring A,
-//     rounds evaluate the Compound tree (rl_hex_prism) and min-merge.
+//   * hexagonal prisms: group bounds -> ring S -> bounding spheres -> ring A; a round decides the Compound tree's
+//     answer by margins (rl_hex_prism_fast, ~330 instructions) and evaluates the tree itself (rl_hex_prism, ~600) only
+//     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2,

@@ -7,12 +7,15 @@
 //
 //   spheres   1 x RlF4 each : {centre.xyz, radius^2}                         geometry.rs:186-200
 //             "direct" spheres first (tested by every ray), then clusters of RL_CLUSTER_K spatially
-//             close spheres, each preceded by a {bounding-sphere centre, radius^2} record
+//             close spheres, each preceded by a {bounding-sphere centre, radius^2} record (on the DEVICE a clustered
+//             sphere's record is {centre.xyz, |centre|^2 - 1.001 radius^2}, see RlSceneView::sphere_r2)
 //   planes    2 x RlF4 each : {normal.xyz, radius^2 or -1}, {offset.xyz, obj} geometry.rs:35-51,130-150
 //   parabs    3 x RlF4 each : {offset.xyz, obj}, {normal.xyz, 0}, {focal_point.xyz, 0}   :269-295
 //   prisms   17 x RlF4 each : 8 half-spaces x ({normal.xyz, 0}, {offset.xyz, obj})       :409-515
+//                             (the fourth components of normal records 0 and 1 hold max |offset|_1 and max |normal|_1:
+//                             the scale of rl_hex_prism_fast's error bound)
 //                             + {bounding-sphere centre.xyz, radius^2} (not in the reference: a
-//                             conservative cull, see rl_prism_bound_pass); the odd stride also keeps
+//                             conservative cull, see rl_bound_pass); the odd stride also keeps
 //                             per-lane prism fetches off a single LDS bank row
 //   objects   2 x RlF4 each : {surface_kind | material_kind << 8, group index, 0, 0} as bits,
 //                             {m0, m1, m2, 0}  (black body: m0 = kelvins, m1 = normalisation factor)
