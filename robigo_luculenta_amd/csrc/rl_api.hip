@@ -184,6 +184,24 @@ int drain_events(RlTraceUnit* u) {
     return RL_OK;
 }
 
+// The instantiation of rl_trace_kernel for a launch: primitives staged in LDS or fetched from global memory, fused with
+// the splat or not, an open launch or a plain one, prisms with a second bound or without.
+typedef void (*TraceKernel)(const RlF4*, RlSceneLayout, RlTraceJob, RlMappedPhoton*, float*, unsigned long long*, const RlJobEntry*,
+                            RlOpenDev*, RlOpenCtl*);
+TraceKernel trace_kernel_variant(bool stage, bool fused, bool open, bool cyl) {
+    static const TraceKernel table[16] = {
+        rl_trace_kernel<false, false, false, false>, rl_trace_kernel<false, false, false, true>,
+        rl_trace_kernel<false, false, true, false>,  rl_trace_kernel<false, false, true, true>,
+        rl_trace_kernel<false, true, false, false>,  rl_trace_kernel<false, true, false, true>,
+        rl_trace_kernel<false, true, true, false>,   rl_trace_kernel<false, true, true, true>,
+        rl_trace_kernel<true, false, false, false>,  rl_trace_kernel<true, false, false, true>,
+        rl_trace_kernel<true, false, true, false>,   rl_trace_kernel<true, false, true, true>,
+        rl_trace_kernel<true, true, false, false>,   rl_trace_kernel<true, true, false, true>,
+        rl_trace_kernel<true, true, true, false>,    rl_trace_kernel<true, true, true, true>,
+    };
+    return table[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)];
+}
+
 // One launch of the trace kernel on u's stream: n_paths paths from first_path on, into `photons` (un-fused) or splatted
 // into plot_unit's buffer (fused).
 int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
@@ -211,8 +229,8 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const size_t blob_bytes = scene->staged_bytes;
     const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     const bool fused = plot != nullptr;
-    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, false> : rl_trace_kernel<true, false, false>)
-                        : (fused ? rl_trace_kernel<false, true, false> : rl_trace_kernel<false, false, false>);
+    const bool cyl = scene->lay.prism_cylinders != 0u;
+    auto kernel = trace_kernel_variant(stage, fused, false, cyl);
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
     if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
@@ -388,6 +406,8 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_prisms = append(fs.prisms);
     lay.off_objects = append(fs.objects);
     lay.off_cull = append(fs.cull_bounds);
+    lay.off_prism_cyl = append(fs.prism_cyl);
+    lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     lay.off_cie = (uint32_t)blob.size();
@@ -670,8 +690,7 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     job.hm1 = (float)(int)u->height - 1.0f;
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
     const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
-    auto kernel = stage ? (fused ? rl_trace_kernel<true, true, true> : rl_trace_kernel<true, false, true>)
-                        : (fused ? rl_trace_kernel<false, true, true> : rl_trace_kernel<false, false, true>);
+    auto kernel = trace_kernel_variant(stage, fused, true, scene->lay.prism_cylinders != 0u);
     const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
     if (x.tuned_kernel != (const void*)kernel || x.tuned_dyn != dyn) { // once per (slot, variant, scene size)
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

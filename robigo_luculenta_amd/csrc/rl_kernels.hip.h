@@ -39,6 +39,7 @@ struct RlSceneLayout {
     uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
     uint32_t n_cluster_groups, n_prism_groups; // RlFlatScene: second level of the cull table
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
+    uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
 };
 
 struct RlTraceJob {
@@ -218,6 +219,20 @@ __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b, float f
     return __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs) <= r.q;
 }
 
+// Second bound of a prism (RlFlatScene::prism_cyl): does the ray's LINE pass within `radius` of the prism's axis?
+//   |co . (D x a)| <= radius |D x a|   with co = c - o = c + m / 2 (m = -2 o), D the cull ray's (scaled) direction.
+// The build's own conservative test (FMA allowed); the radius carries 5 % + 1e-3 and, here, 4e-6 |co|_1 for the rounding
+// of the triple product far from the prism.  A ray along the axis, an unbounded prism (radius = inf) and NaNs pass.
+__device__ __forceinline__ bool rl_cyl_pass(const RlCullRay& r, RlF4 c, RlF3 a) {
+    const float cox = __builtin_fmaf(0.5f, r.m.x, c.x), coy = __builtin_fmaf(0.5f, r.m.y, c.y), coz = __builtin_fmaf(0.5f, r.m.z, c.z);
+    const float crx = __builtin_fmaf(r.d.y, a.z, -(r.d.z * a.y)), cry = __builtin_fmaf(r.d.z, a.x, -(r.d.x * a.z)),
+                crz = __builtin_fmaf(r.d.x, a.y, -(r.d.y * a.x));
+    const float w = __builtin_fmaf(coz, crz, __builtin_fmaf(coy, cry, cox * crx));
+    const float radius = __builtin_fmaf(4.0e-6f, fabsf(cox) + fabsf(coy) + fabsf(coz), c.w);
+    const float cr2 = __builtin_fmaf(crz, crz, __builtin_fmaf(cry, cry, crx * crx));
+    return !(w * w > radius * radius * cr2);
+}
+
 // The owner lane's cull terms (and far bound) for a round: nine values, one wait.
 __device__ __forceinline__ void rl_fetch_cull_ray(uint32_t owner, const RlCullRay& cr, float far, RlCullRay& r, float& r_far) {
     const uint32_t addr = owner << 2;
@@ -274,7 +289,8 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, float sv_cull_cmax2,
+template <bool CYL>
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
@@ -386,7 +402,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }
         for (uint32_t i = full; i < sv.n_direct; ++i) {
             const RlF4 next = sph[i + 1];
-            RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            uint32_t pos = i; // opaque: (full << 6) | lane is loop-invariant over the PERSISTENT loop too, gets hoisted out of
+            asm volatile("" : "+s"(pos)); // it into a vector register that lives through the whole kernel -- and spills
+            RL_SPHERE_REJECT(c0, pos, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             c0 = next;
         }
     }
@@ -440,7 +458,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     const uint32_t n_level1 = RL_GROUP_G * (n_cluster_groups + n_prism_groups);
     // ---- ring S round.  PROCESS_A(count) runs a ring-A round; ITEM_BASE turns a cull-table index into the
     // cluster / prism number.
-#define RL_GROUP_ROUND(COUNT, ITEM_BASE, PROCESS_A)                                                    \
+#define RL_GROUP_ROUND(COUNT, ITEM_BASE, PROCESS_A, CYL)                                                    \
     {                                                                                                   \
         RL_STAT(RL_ST_S_ROUNDS, 1);                                                                     \
         RL_STAT(RL_ST_S_LANES, COUNT);                                                                  \
@@ -455,7 +473,11 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
         _Pragma("nounroll") for (uint32_t j = 0; j < RL_GROUP_G; ++j) {                                 \
             const RlF4 bnd = cull[first + j];                                                           \
-            const bool pass = rl_cull_pass(r, bnd, r_far);                                              \
+            bool pass = rl_cull_pass(r, bnd, r_far);                                                    \
+            if (CYL) { /* wave-uniform: a scene with many prisms tests their second bound too */        \
+                const RlF4* cy = prism_cyl + 2u * (first + j - (ITEM_BASE));                            \
+                pass = pass && rl_cyl_pass(r, cy[0], rl_xyz(cy[1]));                                    \
+            }                                                                                           \
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
             if (m != 0) {                                                                               \
                 if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((first + j - (ITEM_BASE)) << 6) | owner; \
@@ -470,7 +492,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_T1(RL_ST_T_S_ROUNDS, t_s);                                                                   \
     }
     // ---- level 2, wave-uniform: group bounds [FIRST, FIRST + COUNT) of the cull table -> ring S ----
-#define RL_GROUP_CULLS(FIRST_GROUP, N_GROUPS, ITEM_BASE, PROCESS_A)                                     \
+#define RL_GROUP_CULLS(FIRST_GROUP, N_GROUPS, ITEM_BASE, PROCESS_A, CYL)                                     \
     {                                                                                                   \
         const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
         RlF4 g0 = gb[0];                                                                                \
@@ -482,7 +504,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                 if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (((FIRST_GROUP) + g) << 6) | lane;    \
                 s_tail += (uint32_t)__popcll(m);                                                        \
                 if (s_tail - s_head >= 64u) {                                                           \
-                    RL_GROUP_ROUND(64u, ITEM_BASE, PROCESS_A)                                           \
+                    RL_GROUP_ROUND(64u, ITEM_BASE, PROCESS_A, CYL)                                      \
                     s_head += 64u;                                                                      \
                 }                                                                                       \
             }                                                                                           \
@@ -490,13 +512,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }                                                                                               \
         if (s_tail != s_head) {                                                                         \
             const uint32_t left = s_tail - s_head;                                                      \
-            RL_GROUP_ROUND(left, ITEM_BASE, PROCESS_A)                                                  \
+            RL_GROUP_ROUND(left, ITEM_BASE, PROCESS_A, CYL)                                             \
             s_head = s_tail;                                                                            \
         }                                                                                               \
     }
     // ---- sphere clusters: group culls -> ring S -> cluster bounds -> ring A -> members -> ring B ----
     if (n_cluster_groups != 0) {
-        RL_GROUP_CULLS(0u, n_cluster_groups, 0u, process_clusters)
+        RL_GROUP_CULLS(0u, n_cluster_groups, 0u, process_clusters, false)
         RL_STAT(RL_ST_S_ITEMS, s_tail);
         if (a_tail != a_head) process_clusters(a_tail - a_head);
         a_head = a_tail;
@@ -546,7 +568,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_T1(RL_ST_T_P_ROUNDS, t_p);
     };
     if (n_prism_groups != 0) {
-        RL_GROUP_CULLS(n_cluster_groups, n_prism_groups, RL_GROUP_G * n_cluster_groups, process_prisms)
+        RL_GROUP_CULLS(n_cluster_groups, n_prism_groups, RL_GROUP_G * n_cluster_groups, process_prisms, CYL)
     }
 #undef RL_GROUP_CULLS
 #undef RL_GROUP_ROUND
@@ -583,7 +605,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // OPEN: an open launch (see RlOpenDev above): the paths come from a job table that grows while the kernel runs, every lane
 // remembers which job its path belongs to, and finished paths are counted per job.  A compile-time switch so that a
 // plain launch -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
-template <bool STAGE_LDS, bool FUSED, bool OPEN>
+// CYL: the scene's prisms carry a second bound (RlFlatScene::prism_cylinders) -- a compile-time switch so that scenes
+// without it run exactly the code they ran before it existed.
+template <bool STAGE_LDS, bool FUSED, bool OPEN, bool CYL>
 // At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
 // the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
@@ -970,7 +994,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
             continue;
         }
-        const RlHit hit = rl_scan_wave(sv, base + lay.off_cull, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {

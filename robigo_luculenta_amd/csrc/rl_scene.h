@@ -87,6 +87,8 @@ struct RlFlatScene {
     // group's members.  Not in the reference; conservative like the bounds themselves.
     std::vector<RlF4> cull_bounds;
     uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [G * n_cluster_groups][G * n_prism_groups][groups][groups][slack]
+    std::vector<RlF4> prism_cyl;               // 2 records per prism {point on the axis, radius}, {unit axis, 0}; empty unless
+    bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
@@ -96,7 +98,7 @@ struct RlFlatScene {
     std::vector<RlF4> camera_rec; // see RlSceneView
     // Total bytes of the primitive arrays (what RL_FETCH_LDS stages per workgroup).
     size_t staged_bytes() const {
-        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size() + camera_rec.size()) * sizeof(RlF4) +
+        return (spheres.size() + planes.size() + parabs.size() + prisms.size() + objects.size() + cull_bounds.size() + camera_rec.size() + prism_cyl.size()) * sizeof(RlF4) +
                sphere_obj.size() * (sizeof(uint32_t) + sizeof(float));
     }
 };

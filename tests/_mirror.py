@@ -27,6 +27,8 @@ def lib():
         L.mirror_plot.argtypes = [vp, u32, u32, vp, u64]
         L.mirror_prism_fast_check.argtypes = [vp, u64, u64, vp]
         L.mirror_prism_fast_check_paths.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
+        L.mirror_prism_cylinders.restype = u32
+        L.mirror_prism_cylinders.argtypes = [vp, vp, u32]
         L.mirror_prism_pairs.restype = u64
         L.mirror_prism_pairs.argtypes = [vp, u64, u64, vp, vp, vp, u64]
         _lib = L
@@ -82,6 +84,13 @@ def prism_pairs(scene, trials, seed):
     tree = np.zeros((trials, 2), dtype=np.uint32)
     n = lib().mirror_prism_pairs(scene.h, trials, seed, O.ptr(prisms), O.ptr(rays), O.ptr(tree), trials)
     return prisms[:n], rays[:n], tree[:n]
+
+
+def prism_cylinders(scene, cap=4096):
+    """The prisms' second bound as (n, 8) floats {point on the axis, radius, unit axis, 0}; empty when the scene does not use it."""
+    out = np.zeros((cap, 8), dtype=np.float32)
+    n = lib().mirror_prism_cylinders(scene.h, O.ptr(out), cap)
+    return out[:n]
 
 
 def plot(w, h, photons):

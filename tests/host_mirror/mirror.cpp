@@ -327,3 +327,17 @@ extern "C" void mirror_prism_fast_check_paths(void* scene, uint32_t w, uint32_t 
         }
     }
 }
+
+// The prisms' second bound (RlFlatScene::prism_cyl): 8 floats per prism {point.xyz, radius, axis.xyz, 0}; returns the
+// number of prisms, 0 when the scene does not use it (fewer than 40 prisms).
+extern "C" uint32_t mirror_prism_cylinders(void* scene, float* out8, uint32_t cap) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    if (!fs.prism_cylinders) return 0;
+    const uint32_t n = (uint32_t)(fs.prism_cyl.size() / 2);
+    for (uint32_t i = 0; i < n && i < cap; ++i) {
+        const RlF4 c = fs.prism_cyl[2 * i], a = fs.prism_cyl[2 * i + 1];
+        float* o = out8 + 8 * i;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = a.x; o[5] = a.y; o[6] = a.z; o[7] = 0.0f;
+    }
+    return n;
+}

@@ -381,6 +381,25 @@ def test_random_scenes_bit_exact_on_device(seed):
         assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_random_scenes_with_many_prisms_use_the_second_bound_and_stay_bit_exact(seed):
+    """From 40 prisms on the kernel tests a cylinder around every prism's axis besides its bounding sphere (the CYL
+    instantiations of rl_trace_kernel): randomly placed and oriented prisms, both fetch modes, against the oracle."""
+    import _random_scene as RS
+    objs, cam = RS.random_scene(seed, n_spheres=60, n_prisms=48 + seed)
+    scene, oscene = R.Scene(objs, cam), O.Scene(objs.view(O.OBJECT_DTYPE), _ocam(cam))
+    n = 1 << 15
+    want, segs = oscene.render(320, 180, seed, 0, 0, n, threads=4)
+    for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+        t = R.TraceUnit(0, 320, 180, n_photons=n)
+        t.set_fetch(fetch)
+        t.render(scene, seed=seed, stream=0, first_path_index=0)            # an open launch
+        assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[:2] == (n, segs)
+        t.render_async(scene, seed=seed, stream=0, first_path_index=0)      # a plain launch
+        t.sync()
+        assert t.mapped_photons.tobytes() == want.tobytes()
+
+
 def test_cpp_client_of_the_c_abi_renders_a_png(tmp_path):
     """examples/render.cpp: main.rs as a compiled client that links only against the C ABI."""
     import subprocess

@@ -190,3 +190,24 @@ def test_prism_shortcut_on_random_prisms():
         assert r["pairs"] > 500_000 and r["wrong"] == 0, (seed, r)
         p = M.prism_fast_check_paths(sc, 640, 360, seed, 0, 0, 30_000)
         assert p["wrong"] == 0, (seed, p)
+
+
+def test_prism_cylinders_hold_every_hit_and_are_used_only_where_they_pay():
+    """The second conservative bound of a prism (rl_scene.cpp: prism_cylinder) -- a cylinder around its axis -- is built
+    only for scenes with >= 40 prisms (the glass-stress scene's 66; not the built-in scene's 22), and every point where the
+    reference's Compound tree reports a hit lies inside it: culling by it cannot change Scene::intersect's result."""
+    objs, cam = M.builtin_desc(0)
+    assert len(M.prism_cylinders(M.Scene(objs, cam))) == 0
+    objs, cam = M.builtin_desc(1)
+    sc = M.Scene(objs, cam)
+    cyl = M.prism_cylinders(sc)
+    assert len(cyl) == 66 and np.isfinite(cyl).all()
+    assert np.allclose(np.linalg.norm(cyl[:, 4:7], axis=1), 1.0, atol=1e-6) and (cyl[:, 3] > 0.5).all() and (cyl[:, 3] < 2.5).all()
+    prisms, rays, tree = M.prism_pairs(sc, 600_000, 4242)
+    hit = tree[:, 0] != 0xffffffff
+    t = tree[hit, 0].view(np.float32).astype(np.float64)
+    p = rays[hit, :3].astype(np.float64) + rays[hit, 3:].astype(np.float64) * t[:, None]
+    c, r, a = cyl[prisms[hit], :3].astype(np.float64), cyl[prisms[hit], 3].astype(np.float64), cyl[prisms[hit], 4:7].astype(np.float64)
+    d = p - c
+    off_axis = np.sqrt(np.maximum((d * d).sum(1) - (d * a).sum(1) ** 2, 0.0))
+    assert hit.sum() > 150_000 and (off_axis <= r / 1.04).all(), (off_axis / r).max()   # inside, with the inflation to spare

@@ -47,16 +47,16 @@ def usage(tmp_path_factory):
 
 def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage):
     trace = {k: v for k, v in usage.items() if "rl_trace_kernel" in k and k != "__asm__"}
-    assert len(trace) == 8                                            # LDS / global fetch x fused / un-fused x plain / open
+    assert len(trace) == 16                                           # LDS / global fetch x fused / un-fused x plain / open x prisms with / without a second bound
     for name, u in trace.items():
         assert u["VGPRs"] <= 120 and u.get("AGPRs", 0) == 0, (name, u)
         assert u["Occupancy"] == 4, (name, u)
-    # nothing spills to memory in ANY variant -- the OPEN ones are what the drop-in's blocking calls run --
+    # nothing spills to memory in ANY of the sixteen variants -- the OPEN ones are what the drop-in's blocking calls run --
     # and the scalar registers that do not fit (launch constants, written once to lanes of a vector register and read
     # back where they are used) stay bounded: the LDS variants have 32-bit scene addresses, the global ones 64-bit
     for name, u in trace.items():
         assert u["ScratchSize"] == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
-        lds, is_open = "ILb1E" in name, "Lb1EEvPK4RlF4" in name
+        lds, _, is_open, _ = (c == "1" for c in re.search(r"ILb([01])ELb([01])ELb([01])ELb([01])E", name).groups())
         assert u["SGPRs Spill"] <= (40 if lds and not is_open else 56 if lds else 72), (name, u)
 
 
@@ -73,9 +73,9 @@ def test_open_variants_wait_for_their_results_before_counting_them(usage):
     site it is inlined or merged into), and in none of the plain ones (which never count per call)."""
     text = usage["__asm__"]
     bodies = {}
-    for m in re.finditer(r"\n(_Z15rl_trace_kernelILb[01]ELb[01]ELb([01])E\w+):(.*?)s_endpgm", text, re.S):
+    for m in re.finditer(r"\n(_Z15rl_trace_kernelILb[01]ELb[01]ELb([01])ELb[01]E\w+):(.*?)s_endpgm", text, re.S):
         bodies[m.group(1)] = (m.group(2) == "1", m.group(3))
-    assert len(bodies) == 8
+    assert len(bodies) == 16
     for name, (is_open, body) in bodies.items():
         n = len(re.findall(r"s_waitcnt vmcnt\(0\) ; rl_settle", body))
         assert (n >= 1) if is_open else (n == 0), (name, n)   # (the compiler may merge settle()'s call sites into one)

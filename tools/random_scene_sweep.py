@@ -30,7 +30,7 @@ bad, rays, t0 = 0, 0, time.time()
 sizes = []
 for k in range(scenes):
     n_spheres = int(rng.choice([3, 9, 25, 39, 40, 41, 77, 130, 200, 333, 512, 800]))
-    n_prisms = int(rng.choice([0, 0, 1, 2, 5, 9, 17, 30]))
+    n_prisms = int(rng.choice([0, 0, 1, 2, 5, 9, 17, 30, 45, 80]))   # from 40 on: the prisms' second bound (CYL kernels)
     objs, cam = random_scene(1000 + k, n_spheres=n_spheres, n_prisms=n_prisms, n_planes=int(rng.integers(0, 4)),
                              n_circles=int(rng.integers(0, 4)), n_parabs=int(rng.integers(0, 3)))
     scene = R.Scene(objs, cam)
