@@ -408,6 +408,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_cull = append(fs.cull_bounds);
     lay.off_prism_cyl = append(fs.prism_cyl);
     lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
+    lay.group_gc = fs.group_gc;
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     lay.off_cie = (uint32_t)blob.size();

@@ -40,6 +40,7 @@ struct RlSceneLayout {
     uint32_t n_cluster_groups, n_prism_groups; // RlFlatScene: second level of the cull table
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
+    uint32_t group_gc;                         // RlFlatScene::group_gc: clusters per group of the cull table
 };
 
 struct RlTraceJob {
@@ -290,7 +291,7 @@ struct RlOpenWg {
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
 template <bool CYL>
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, float sv_cull_cmax2,
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
@@ -451,14 +452,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_T1(RL_ST_T_A_ROUNDS, t_a);
     };
 
-    // The cull table (rl_scene.h): level-1 bounds [clusters | prisms], then one group bound per RL_GROUP_G of them.
+    // The cull table (rl_scene.h): level-1 bounds [clusters | prisms], then one group bound per group_gc clusters / RL_GROUP_GP prisms.
     // Every ray is tested against the GROUP bounds with wave-uniform records; the (group, ray) pairs that pass are
-    // compacted into ring S and a ring-S round tests the group's RL_GROUP_G members, one pair per lane with the
+    // compacted into ring S and a ring-S round tests the group's members, one pair per lane with the
     // owner's cull terms fetched across lanes, pushing the members that pass to ring A (clusters or prisms).
-    const uint32_t n_level1 = RL_GROUP_G * (n_cluster_groups + n_prism_groups);
+    const uint32_t n_level1 = group_gc * n_cluster_groups + RL_GROUP_GP * n_prism_groups;
     // ---- ring S round.  PROCESS_A(count) runs a ring-A round; ITEM_BASE turns a cull-table index into the
     // cluster / prism number.
-#define RL_GROUP_ROUND(COUNT, ITEM_BASE, PROCESS_A, CYL)                                                    \
+#define RL_GROUP_ROUND(COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                                    \
     {                                                                                                   \
         RL_STAT(RL_ST_S_ROUNDS, 1);                                                                     \
         RL_STAT(RL_ST_S_LANES, COUNT);                                                                  \
@@ -466,12 +467,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();                                                                                 \
         const uint32_t e = ring_s[(s_head + lane) & 127u];                                              \
         const uint32_t owner = e & 63u;                                                                 \
-        const uint32_t first = RL_GROUP_G * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
+        const uint32_t first = (ITEM_BASE) + (G) * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
         RlCullRay r;                                                                                    \
         float r_far;                                                                                    \
         rl_fetch_cull_ray(owner, cr, far, r, r_far);                                                    \
         if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
-        _Pragma("nounroll") for (uint32_t j = 0; j < RL_GROUP_G; ++j) {                                 \
+        _Pragma("nounroll") for (uint32_t j = 0; j < (G); ++j) {                                        \
             const RlF4 bnd = cull[first + j];                                                           \
             bool pass = rl_cull_pass(r, bnd, r_far);                                                    \
             if (CYL) { /* wave-uniform: a scene with many prisms tests their second bound too */        \
@@ -492,7 +493,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_T1(RL_ST_T_S_ROUNDS, t_s);                                                                   \
     }
     // ---- level 2, wave-uniform: group bounds [FIRST, FIRST + COUNT) of the cull table -> ring S ----
-#define RL_GROUP_CULLS(FIRST_GROUP, N_GROUPS, ITEM_BASE, PROCESS_A, CYL)                                     \
+#define RL_GROUP_CULLS(FIRST_GROUP, N_GROUPS, G, ITEM_BASE, PROCESS_A, CYL)                                     \
     {                                                                                                   \
         const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
         RlF4 g0 = gb[0];                                                                                \
@@ -501,10 +502,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             const bool pass = rl_cull_pass(cr, g0, far);                                                \
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
             if (m != 0) {                                                                               \
-                if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (((FIRST_GROUP) + g) << 6) | lane;    \
+                if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (g << 6) | lane; /* group number within its kind */ \
                 s_tail += (uint32_t)__popcll(m);                                                        \
                 if (s_tail - s_head >= 64u) {                                                           \
-                    RL_GROUP_ROUND(64u, ITEM_BASE, PROCESS_A, CYL)                                      \
+                    RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                   \
                     s_head += 64u;                                                                      \
                 }                                                                                       \
             }                                                                                           \
@@ -512,13 +513,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }                                                                                               \
         if (s_tail != s_head) {                                                                         \
             const uint32_t left = s_tail - s_head;                                                      \
-            RL_GROUP_ROUND(left, ITEM_BASE, PROCESS_A, CYL)                                             \
+            RL_GROUP_ROUND(left, G, ITEM_BASE, PROCESS_A, CYL)                                          \
             s_head = s_tail;                                                                            \
         }                                                                                               \
     }
     // ---- sphere clusters: group culls -> ring S -> cluster bounds -> ring A -> members -> ring B ----
     if (n_cluster_groups != 0) {
-        RL_GROUP_CULLS(0u, n_cluster_groups, 0u, process_clusters, false)
+        RL_GROUP_CULLS(0u, n_cluster_groups, group_gc, 0u, process_clusters, false)
         RL_STAT(RL_ST_S_ITEMS, s_tail);
         if (a_tail != a_head) process_clusters(a_tail - a_head);
         a_head = a_tail;
@@ -568,7 +569,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_T1(RL_ST_T_P_ROUNDS, t_p);
     };
     if (n_prism_groups != 0) {
-        RL_GROUP_CULLS(n_cluster_groups, n_prism_groups, RL_GROUP_G * n_cluster_groups, process_prisms, CYL)
+        RL_GROUP_CULLS(n_cluster_groups, n_prism_groups, RL_GROUP_GP, group_gc * n_cluster_groups, process_prisms, CYL)
     }
 #undef RL_GROUP_CULLS
 #undef RL_GROUP_ROUND
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
             continue;
         }
-        const RlHit hit = rl_scan_wave<CYL>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {

@@ -374,15 +374,15 @@ RlF4 cluster_bound(const std::vector<SphereIn>& sph, const std::vector<uint32_t>
     return b;
 }
 
-// ---- second level of the cull table: groups of RL_GROUP_G neighbouring bounds ------------------------------
+// ---- second level of the cull table: groups of G neighbouring bounds (G = RlFlatScene::group_gc clusters or RL_GROUP_GP prisms) ------------------------------
 
 double bound_radius(const RlF4& b) { return b.w > 0.0f ? std::sqrt((double)b.w) : 0.0; } // {c, R^2}; R^2 = +inf -> inf
 
-// Partitions bounds (given as {centre, radius^2}) into groups of at most RL_GROUP_G: recursive median cuts along the
-// longest axis into leaves of exactly RL_GROUP_G (the last may be short), then a few rounds of capacity-limited
+// Partitions bounds (given as {centre, radius^2}) into groups of at most G: recursive median cuts along the
+// longest axis into leaves of exactly G (the last may be short), then a few rounds of capacity-limited
 // re-assignment to the nearest group centre (the same scheme as the sphere clusters above).
-void split_groups(const std::vector<RlF4>& b, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out) {
-    if (idx.size() <= RL_GROUP_G) {
+void split_groups(const std::vector<RlF4>& b, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out, size_t G) {
+    if (idx.size() <= G) {
         if (!idx.empty()) out.push_back(idx);
         return;
     }
@@ -399,13 +399,13 @@ void split_groups(const std::vector<RlF4>& b, std::vector<uint32_t> idx, std::ve
         if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
     auto coord = [&](uint32_t i) { return axis == 0 ? b[i].x : axis == 1 ? b[i].y : b[i].z; };
     std::sort(idx.begin(), idx.end(), [&](uint32_t p, uint32_t q) { return coord(p) < coord(q) || (coord(p) == coord(q) && p < q); });
-    size_t left = ((idx.size() / 2 + RL_GROUP_G - 1) / RL_GROUP_G) * RL_GROUP_G;
-    if (left >= idx.size()) left = idx.size() - RL_GROUP_G;
-    split_groups(b, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out);
-    split_groups(b, std::vector<uint32_t>(idx.begin() + left, idx.end()), out);
+    size_t left = ((idx.size() / 2 + G - 1) / G) * G;
+    if (left >= idx.size()) left = idx.size() - G;
+    split_groups(b, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out, G);
+    split_groups(b, std::vector<uint32_t>(idx.begin() + left, idx.end()), out, G);
 }
 
-void refine_groups(const std::vector<RlF4>& b, std::vector<std::vector<uint32_t>>& groups) {
+void refine_groups(const std::vector<RlF4>& b, std::vector<std::vector<uint32_t>>& groups, size_t G) {
     const size_t k = groups.size();
     if (k < 2) return;
     std::vector<uint32_t> all;
@@ -441,7 +441,7 @@ void refine_groups(const std::vector<RlF4>& b, std::vector<std::vector<uint32_t>
             size_t pick = k;
             double pick_d = 1e300;
             for (size_t j = 0; j < k; ++j) {
-                if (next[j].size() >= RL_GROUP_G) continue;
+                if (next[j].size() >= G) continue;
                 const double d = dist2(i, j);
                 if (d < pick_d) { pick_d = d; pick = j; }
             }
@@ -499,12 +499,12 @@ RlF4 group_bound(const std::vector<RlF4>& b, const std::vector<uint32_t>& member
 
 // Orders `bounds` so that each group's members are consecutive; returns the new order (old indices) and, per
 // group, its members as positions in the new order.
-std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vector<std::vector<uint32_t>>* groups_out) {
+std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vector<std::vector<uint32_t>>* groups_out, size_t G) {
     std::vector<uint32_t> idx(bounds.size());
     std::iota(idx.begin(), idx.end(), 0u);
     std::vector<std::vector<uint32_t>> groups;
-    split_groups(bounds, idx, groups);
-    refine_groups(bounds, groups);
+    split_groups(bounds, idx, groups, G);
+    refine_groups(bounds, groups, G);
     std::vector<uint32_t> order;
     for (std::vector<uint32_t>& g : groups) {
         std::sort(g.begin(), g.end());
@@ -649,18 +649,19 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     std::vector<std::vector<uint32_t>> clusters;
     split_clusters(sph_in, clustered, clusters);
     refine_clusters(sph_in, clusters);
-    // Second level: clusters whose bounds are neighbours become consecutive, RL_GROUP_G per group; a short group is
+    fs.group_gc = clusters.size() > RL_GROUP_GC_MANY ? 4u : 3u;
+    // Second level: clusters whose bounds are neighbours become consecutive, group_gc per group; a short group is
     // filled up with never-reached dummy clusters so that a cluster's number is also its position in the cull table.
     const RlF4 never = dummy; // as a bound {c, R^2 = -inf}: fails every cull test, host and device
     {
         std::vector<RlF4> bounds;
         for (std::vector<uint32_t>& members : clusters) bounds.push_back(cluster_bound(sph_in, members));
         std::vector<std::vector<uint32_t>> groups;
-        order_by_groups(bounds, &groups);
+        order_by_groups(bounds, &groups, fs.group_gc);
         std::vector<std::vector<uint32_t>> padded;
         for (const std::vector<uint32_t>& g : groups) {
             for (uint32_t k : g) padded.push_back(clusters[k]);
-            for (size_t pad = g.size(); pad < RL_GROUP_G; ++pad) padded.push_back(std::vector<uint32_t>());
+            for (size_t pad = g.size(); pad < fs.group_gc; ++pad) padded.push_back(std::vector<uint32_t>());
         }
         clusters = padded;
     }
@@ -675,7 +676,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         }
     }
     fs.n_clusters = (uint32_t)clusters.size();
-    fs.n_cluster_groups = fs.n_clusters / RL_GROUP_G;
+    fs.n_cluster_groups = fs.n_clusters / fs.group_gc;
     // The prisms likewise: reorder the records (scan order is irrelevant: ties are broken by the object index each
     // record carries), fill short groups with dummy prisms, point the prism objects at their new position.
     uint32_t n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
@@ -683,7 +684,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         std::vector<RlF4> bounds;
         for (uint32_t i = 0; i < n_prisms; ++i) bounds.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
         std::vector<std::vector<uint32_t>> groups;
-        order_by_groups(bounds, &groups);
+        order_by_groups(bounds, &groups, RL_GROUP_GP);
         std::vector<RlF4> sorted;
         for (const std::vector<uint32_t>& g : groups) {
             for (uint32_t k : g) {
@@ -691,7 +692,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
                 fs.objects[2 * rl_f2u(pr[1].w)].y = rl_u2f((uint32_t)(sorted.size() / RL_PRISM_STRIDE)); // group index = position
                 sorted.insert(sorted.end(), pr, pr + RL_PRISM_STRIDE);
             }
-            for (size_t pad = g.size(); pad < RL_GROUP_G; ++pad) {
+            for (size_t pad = g.size(); pad < RL_GROUP_GP; ++pad) {
                 sorted.resize(sorted.size() + RL_PRISM_STRIDE - 1, RlF4{0.0f, 0.0f, 0.0f, 0.0f});
                 sorted.push_back(never);
             }
@@ -699,7 +700,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         fs.prisms = sorted;
         n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
     }
-    fs.n_prism_groups = n_prisms / RL_GROUP_G;
+    fs.n_prism_groups = n_prisms / RL_GROUP_GP;
     // second bound per prism (in the prisms' final order); worth its 26 instructions per bound test only when the pairs that
     // pass the spheres fill more than one round per iteration: from ~40 prisms on (the glass-stress scene: 66, 2.2 pairs per
     // ray; the built-in scene: 22, 0.6)
@@ -714,8 +715,8 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     }
     fs.prism_cylinders = real_prisms >= 40u;
     if (!fs.prism_cylinders) fs.prism_cyl.clear();
-    // Cull table for the kernel, {c, |c|^2 - R^2} per bound: clusters, prisms, then one group bound per RL_GROUP_G
-    // clusters and per RL_GROUP_G prisms.
+    // Cull table for the kernel, {c, |c|^2 - R^2} per bound: clusters, prisms, then one group bound per group_gc
+    // clusters and per RL_GROUP_GP prisms.
     fs.cull_cmax2 = 0.0f;
     auto add_bound = [&](const RlF4& b) {
         const double c2 = (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z;
@@ -728,11 +729,14 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     for (uint32_t k = 0; k < fs.n_clusters; ++k) level1.push_back(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
     for (uint32_t i = 0; i < n_prisms; ++i) level1.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
     for (const RlF4& b : level1) add_bound(b);
-    for (size_t first = 0; first < level1.size(); first += RL_GROUP_G) {
+    const size_t n_cluster_level1 = (size_t)fs.group_gc * fs.n_cluster_groups;
+    for (size_t first = 0; first < level1.size();) {
+        const size_t G = first < n_cluster_level1 ? fs.group_gc : RL_GROUP_GP;
         std::vector<uint32_t> members;
-        for (size_t j = first; j < first + RL_GROUP_G; ++j)
+        for (size_t j = first; j < first + G; ++j)
             if (!(level1[j].w == never.w)) members.push_back((uint32_t)j);
         add_bound(members.empty() ? never : group_bound(level1, members));
+        first += G;
     }
     fs.cull_bounds.push_back(dummy); // slack for the kernel's prefetch
     fs.cull_bounds.push_back(dummy);

@@ -46,8 +46,14 @@ struct alignas(16) RlF4 {
 #define RL_CLUSTER_K 10                        // spheres per cluster (tuned on MI355X: DESIGN.md)
 #endif
 #define RL_CLUSTER_STRIDE (RL_CLUSTER_K + 1)   // + the bound record in front (odd stride: LDS banks)
-#ifndef RL_GROUP_G
-#define RL_GROUP_G 3                           // bounds per second-level group of the cull table (tuned: DESIGN.md)
+// Bounds per second-level group of the cull table, tuned on MI355X.  Clusters: threes up to 40 clusters, fours
+// beyond (RlFlatScene::group_gc: the 513-object scene, 49 clusters, gains 3 % with fours; the built-in one, 32, loses 0.3 %).
+// Prisms: threes (the glass-stress scene loses 2.5 % with fours).
+#ifndef RL_GROUP_GC_MANY
+#define RL_GROUP_GC_MANY 40
+#endif
+#ifndef RL_GROUP_GP
+#define RL_GROUP_GP 3
 #endif
 
 // Everything the per-path code needs to read; pointers are device or host memory depending on
@@ -80,13 +86,14 @@ struct RlFlatScene {
     std::vector<RlF4> spheres, planes, parabs, prisms, objects;
     // Device-only cull table, every bound as {centre.xyz, |centre|^2 - radius^2}: the form the kernel's expanded cull
     // test consumes (rl_kernels.hip.h).  Two levels: the cluster bounds, then the prism bounds, each list padded to
-    // a multiple of RL_GROUP_G with never-reached dummies and ordered so that RL_GROUP_G consecutive entries are
+    // a multiple of the group size (group_gc clusters, RL_GROUP_GP prisms) with never-reached dummies and ordered so that the entries of a group are
     // spatial neighbours (clusters and prisms are stored in that order too); then one GROUP bound -- the bounding
-    // sphere of the RL_GROUP_G bounds it covers -- per group of clusters, then per group of prisms.  A ray is tested
+    // sphere of the bounds it covers -- per group of clusters, then per group of prisms.  A ray is tested
     // against the group bounds in a wave-uniform loop and only the (group, ray) pairs that pass go on to the
     // group's members.  Not in the reference; conservative like the bounds themselves.
     std::vector<RlF4> cull_bounds;
-    uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [G * n_cluster_groups][G * n_prism_groups][groups][groups][slack]
+    uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [group_gc * n_cluster_groups][GP * n_prism_groups][groups][groups][slack]
+    uint32_t group_gc = 3;                     // clusters per group (3 or 4, see RL_GROUP_GC_MANY)
     std::vector<RlF4> prism_cyl;               // 2 records per prism {point on the axis, radius}, {unit axis, 0}; empty unless
     bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene

@@ -141,13 +141,18 @@ extern "C" uint32_t mirror_bounds(void* scene, float* out4, uint32_t cap, uint32
     return n;
 }
 
-// The second level of the cull table: one bound {centre, radius^2} per RL_GROUP_G consecutive level-1 bounds
-// (reconstructed from the {c, |c|^2 - R^2} records the kernel reads).  Returns the number of groups.
-extern "C" uint32_t mirror_group_bounds(void* scene, float* out4, uint32_t cap, uint32_t* group_size) {
+// The second level of the cull table: one bound {centre, radius^2} per group of consecutive level-1 bounds -- RlFlatScene::group_gc
+// clusters or RL_GROUP_GP prisms -- (reconstructed from the {c, |c|^2 - R^2} records the kernel reads).  Returns the
+// number of groups; sizes[0..2] = {clusters per group, prisms per group, number of cluster groups}.
+extern "C" uint32_t mirror_group_bounds(void* scene, float* out4, uint32_t cap, uint32_t* sizes) {
     const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
-    const uint32_t n_level1 = RL_GROUP_G * (fs.n_cluster_groups + fs.n_prism_groups);
+    const uint32_t n_level1 = fs.group_gc * fs.n_cluster_groups + RL_GROUP_GP * fs.n_prism_groups;
     const uint32_t n_groups = fs.n_cluster_groups + fs.n_prism_groups;
-    if (group_size) *group_size = RL_GROUP_G;
+    if (sizes) {
+        sizes[0] = fs.group_gc;
+        sizes[1] = RL_GROUP_GP;
+        sizes[2] = fs.n_cluster_groups;
+    }
     for (uint32_t g = 0; g < n_groups && g < cap; ++g) {
         const RlF4 r = fs.cull_bounds[n_level1 + g];
         const double c2 = (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z;

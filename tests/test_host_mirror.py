@@ -124,6 +124,7 @@ def test_cull_table_is_conservative_by_construction():
     scenes = [M.builtin_desc(0, 0), M.builtin_desc(1, 0), M.builtin_desc(0, 158)]
     scenes += [random_scene(seed, n_spheres=90 + 37 * seed, n_prisms=3 + 2 * seed) for seed in range(4)]
     checked = 0
+    group_sizes = []
     for objs, cam in scenes:
         sc = M.Scene(objs, cam)
         b = np.zeros((2048, 4), np.float32)
@@ -131,12 +132,15 @@ def test_cull_table_is_conservative_by_construction():
         nb = L.mirror_bounds(sc.h, O.ptr(b), len(b), C.byref(nc))
         b = b[:nb].astype(np.float64)
         g = np.zeros((1024, 4), np.float32)
-        G = C.c_uint32(0)
-        ng = L.mirror_group_bounds(sc.h, O.ptr(g), len(g), C.byref(G))
-        g, G = g[:ng].astype(np.float64), G.value
-        assert nb == ng * G and nc.value % G == 0
+        sizes = (C.c_uint32 * 3)()
+        ng = L.mirror_group_bounds(sc.h, O.ptr(g), len(g), sizes)
+        g = g[:ng].astype(np.float64)
+        gc, gp, ncg = sizes[0], sizes[1], sizes[2]          # clusters per group, prisms per group, cluster groups
+        assert nb == gc * ncg + gp * (ng - ncg) and nc.value == gc * ncg
+        group_sizes.append((gc, gp))
         for k in range(ng):
-            members = b[G * k: G * k + G]
+            first = gc * k if k < ncg else gc * ncg + gp * (k - ncg)
+            members = b[first: first + (gc if k < ncg else gp)]
             real = members[np.isfinite(members[:, 3]) & (members[:, 3] > 0)]
             assert len(real) >= 1                                  # a group is never all padding
             if not np.isfinite(g[k, 3]):
@@ -155,6 +159,9 @@ def test_cull_table_is_conservative_by_construction():
             big = radii > 4 * np.median(radii)                     # the direct list
             assert inside_some[~big].all()
     assert checked > 150
+    # threes up to RL_GROUP_GC_MANY (40) clusters, fours beyond: the built-in scene (32 clusters), its glass variant, the
+    # 513-object scene (49 clusters)
+    assert group_sizes[:3] == [(3, 3), (3, 3), (4, 3)]
 
 
 # ---- the prism shortcut (rl_hex_prism_fast) against the Compound tree it stands in for (geometry.rs:380-407) ----------
