@@ -426,6 +426,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.n_direct_padded = fs.n_direct_padded;
     lay.cluster_base = fs.cluster_base;
     lay.n_clusters = fs.n_clusters;
+    lay.cluster_k = fs.cluster_k;
     lay.n_cluster_groups = fs.n_cluster_groups;
     lay.n_prism_groups = fs.n_prism_groups;
     lay.n_planes = (uint32_t)(fs.planes.size() / 2);

@@ -486,9 +486,9 @@ RL_HD RlHit rl_scan(const RlSceneView& sv, RlF3 o, RlF3 dir) {
     };
     for (uint32_t i = 0; i < sv.n_direct; ++i) sphere_test(i);
     for (uint32_t k = 0; k < sv.n_clusters; ++k) {
-        const uint32_t base = sv.cluster_base + RL_CLUSTER_STRIDE * k;
+        const uint32_t base = sv.cluster_base + (sv.cluster_k + 1u) * k;
         if (!rl_bound_pass(sv.spheres[base], o, dir)) continue;
-        for (uint32_t j = 1; j <= RL_CLUSTER_K; ++j) sphere_test(base + j);
+        for (uint32_t j = 1; j <= sv.cluster_k; ++j) sphere_test(base + j);
     }
 
     // Paraboloids.

@@ -36,7 +36,7 @@ struct RlSceneLayout {
     // Offsets into the scene blob, in RlF4 units.  Spheres start at 0.
     uint32_t off_planes, off_parabs, off_prisms, off_objects, off_cull, off_camera, off_cie, off_sphere_obj, total_f4;
     float cull_cmax2; // RlFlatScene::cull_cmax2
-    uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters;
+    uint32_t n_planes, n_parabs, n_prisms, n_objects, n_direct, n_direct_padded, cluster_base, n_clusters, cluster_k;
     uint32_t n_cluster_groups, n_prism_groups; // RlFlatScene: second level of the cull table
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
@@ -282,7 +282,7 @@ struct RlOpenWg {
 //   * direct spheres: reject = sign bits of the discriminant q and of d.co (16 flops + 3 int ops,
 //     geometry.rs:204-216 in the scaled form of rl_core.h) -> ring B;
 //   * sphere clusters (rl_scene.h): group bounds (wave-uniform) -> ring S; a ring-S round tests the group's cluster
-//     bounds -> ring A; a ring-A round tests the cluster's RL_CLUSTER_K members, all with the conservative cull test
+//     bounds -> ring A; a ring-A round tests the cluster's members (RlSceneView::cluster_k of them), all with the conservative cull test
 //     (rl_cull_pass: far bound included) -> ring B;
 //   * ring B rounds: exact IEEE sqrt / root selection (geometry.rs:217-240), then min-merge;
 //   * hexagonal prisms: group bounds -> ring S -> bounding spheres -> ring A; a round decides the Compound tree's
@@ -428,25 +428,44 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t e = ring_a[(a_head + lane) & 127u];
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
-        const uint32_t first = sv.cluster_base + RL_CLUSTER_STRIDE * (lane < count ? (e >> 6) : 0u) + 1u;
+        const uint32_t first = sv.cluster_base + (sv.cluster_k + 1u) * (lane < count ? (e >> 6) : 0u) + 1u;
         RlCullRay r;
         float r_far;
         rl_fetch_cull_ray(owner, cr, far, r, r_far);
         if (lane >= count) r.q = -__builtin_inff(); // lanes beyond the round never push
-        RlF4 mb = sph[first];
-        for (uint32_t j = 0; j < RL_CLUSTER_K; ++j) {
-            const RlF4 mb_next = sph[first + (j + 1 < RL_CLUSTER_K ? j + 1 : j)]; // one record of prefetch
-            const bool cand = rl_cull_pass(r, mb, r_far);
-            const uint64_t m = __builtin_amdgcn_ballot_w64(cand);
-            if (m != 0) {
-                if (cand) ring_b[(b_tail + rl_mbcnt(m)) & 127u] = ((first + j) << 6) | owner;
-                b_tail += (uint32_t)__popcll(m);
-                if (b_tail - b_head >= 64u) {
-                    process_spheres(64u);
-                    b_head += 64u;
-                }
+        // The members that pass are collected as one bit per member in a lane-private mask (one v_addc per member: shift
+        // left, carry in the compare mask) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
+        // per pair, so two or three steps replace ten ballot / count / write sequences.
+        uint32_t passed = 0;
+        const uint32_t n_members = sv.cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
+        // MEMBERS(N): the loop over N members, N a constant where it is one of the sizes rl_scene.cpp chooses from -- unrolled,
+        // the members' addresses are immediates -- and n_members otherwise (a build that forces another size: rolled, ~2 % slower).
+#define RL_MEMBERS(N)                                                                                                    \
+        {                                                                                                                \
+            RlF4 mb = sph[first];                                                                                        \
+            for (uint32_t j = 0; j < (N); ++j) {                                                                         \
+                const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
+                const uint64_t m = __builtin_amdgcn_ballot_w64(rl_cull_pass(r, mb, r_far));                              \
+                uint64_t carry_out;                                                                                      \
+                asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(passed), "=s"(carry_out) : "s"(m)); /* member j ends up at bit N - 1 - j */ \
+                mb = mb_next;                                                                                            \
+            }                                                                                                            \
+        }
+        if (n_members == 10u) RL_MEMBERS(10u)
+        else if (n_members == 14u) RL_MEMBERS(14u)
+        else RL_MEMBERS(n_members)
+#undef RL_MEMBERS
+        uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
+        while (any != 0) {
+            const uint32_t j = (n_members - 1u) - (uint32_t)__builtin_ctz(passed);
+            if (passed != 0u) ring_b[(b_tail + rl_mbcnt(any)) & 127u] = ((first + j) << 6) | owner;
+            b_tail += (uint32_t)__popcll(any);
+            passed &= passed - 1u;
+            if (b_tail - b_head >= 64u) {
+                process_spheres(64u);
+                b_head += 64u;
             }
-            mb = mb_next;
+            any = __builtin_amdgcn_ballot_w64(passed != 0u);
         }
         rl_wave_sync();
         RL_T1(RL_ST_T_A_ROUNDS, t_a);
@@ -638,6 +657,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     sv.n_direct_padded = lay.n_direct_padded;
     sv.cluster_base = lay.cluster_base;
     sv.n_clusters = lay.n_clusters;
+    sv.cluster_k = lay.cluster_k;
     sv.n_planes = lay.n_planes;
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -255,10 +256,10 @@ struct SphereIn {
     double radius;
 };
 
-// Splits sphere indices into spatially compact groups of at most RL_CLUSTER_K by recursive median
+// Splits sphere indices into spatially compact groups of at most K by recursive median
 // cuts along the longest axis of the centres.
-void split_clusters(const std::vector<SphereIn>& sph, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out) {
-    if (idx.size() <= RL_CLUSTER_K) {
+void split_clusters(const std::vector<SphereIn>& sph, std::vector<uint32_t> idx, std::vector<std::vector<uint32_t>>& out, size_t K) {
+    if (idx.size() <= K) {
         if (!idx.empty()) out.push_back(idx);
         return;
     }
@@ -275,16 +276,16 @@ void split_clusters(const std::vector<SphereIn>& sph, std::vector<uint32_t> idx,
         if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
     auto coord = [&](uint32_t i) { return axis == 0 ? sph[i].rec.x : axis == 1 ? sph[i].rec.y : sph[i].rec.z; };
     std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return coord(a) < coord(b) || (coord(a) == coord(b) && a < b); });
-    size_t left = ((idx.size() / 2 + RL_CLUSTER_K - 1) / RL_CLUSTER_K) * RL_CLUSTER_K; // full leaves on the left
-    if (left >= idx.size()) left = idx.size() - RL_CLUSTER_K;
-    split_clusters(sph, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out);
-    split_clusters(sph, std::vector<uint32_t>(idx.begin() + left, idx.end()), out);
+    size_t left = ((idx.size() / 2 + K - 1) / K) * K; // full leaves on the left
+    if (left >= idx.size()) left = idx.size() - K;
+    split_clusters(sph, std::vector<uint32_t>(idx.begin(), idx.begin() + left), out, K);
+    split_clusters(sph, std::vector<uint32_t>(idx.begin() + left, idx.end()), out, K);
 }
 
 // Balanced k-means refinement of the kd-split: keeps the number of clusters, caps every cluster at
-// RL_CLUSTER_K members, and re-assigns spheres to the nearest centroid with room (most decided first).
+// K members, and re-assigns spheres to the nearest centroid with room (most decided first).
 // On the demo scene this cuts the clusters a ray reaches from ~2.5 to ~1.6.
-void refine_clusters(const std::vector<SphereIn>& sph, std::vector<std::vector<uint32_t>>& clusters) {
+void refine_clusters(const std::vector<SphereIn>& sph, std::vector<std::vector<uint32_t>>& clusters, size_t K) {
     const size_t k = clusters.size();
     if (k < 2) return;
     std::vector<uint32_t> all;
@@ -321,11 +322,11 @@ void refine_clusters(const std::vector<SphereIn>& sph, std::vector<std::vector<u
             size_t pick = k;
             double pick_d = 1e300;
             for (size_t j = 0; j < k; ++j) {
-                if (next[j].size() >= RL_CLUSTER_K) continue;
+                if (next[j].size() >= K) continue;
                 const double d = dist2(i, j);
                 if (d < pick_d) { pick_d = d; pick = j; }
             }
-            next[pick].push_back(i); // k * RL_CLUSTER_K >= number of spheres, so a slot always exists
+            next[pick].push_back(i); // k * K >= number of spheres, so a slot always exists
         }
         bool same = true;
         for (size_t j = 0; j < k && same; ++j) {
@@ -341,6 +342,128 @@ void refine_clusters(const std::vector<SphereIn>& sph, std::vector<std::vector<u
     for (auto& c : clusters)
         if (!c.empty()) kept.push_back(c);
     clusters = kept;
+}
+
+// ---- local search on a partition of spheres into bins of bounded size ------------------------------------------------
+// Both levels of the cull table are the same problem: put spheres {centre, radius} -- the scene's spheres into clusters,
+// the cluster / prism bounds into groups -- into bins of at most `capacity` so that a ray reaches few bins.  A random
+// line that crosses the scene meets a convex body with a probability proportional to its surface area, so the
+// expected number of bins a ray reaches is proportional to the SUM OF THE BINS' SQUARED BOUNDING RADII: that is what this
+// minimises, starting from the median-cut + capacity-limited k-means partition, by moving one item to a neighbouring
+// bin with room or exchanging two items between neighbouring bins while that lowers the sum.  (The start alone is at
+// the mercy of how the item count divides: on the built-in scene its sum varies by 40 % between cluster sizes 10 .. 16.)
+// Deterministic; changes which bounds a ray is tested against, never a result.
+struct Ball {
+    double c[3], r;
+};
+// Squared radius of (nearly) the smallest ball around `members`: "step towards the farthest member", as cluster_bound.
+double bin_radius2(const std::vector<Ball>& items, const std::vector<uint32_t>& members) {
+    if (members.empty()) return 0.0;
+    double c[3] = {0, 0, 0};
+    for (uint32_t i : members)
+        for (int a = 0; a < 3; ++a) c[a] += items[i].c[a];
+    for (int a = 0; a < 3; ++a) c[a] /= (double)members.size();
+    auto reach = [&](uint32_t i) {
+        const double dx = items[i].c[0] - c[0], dy = items[i].c[1] - c[1], dz = items[i].c[2] - c[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz) + items[i].r;
+    };
+    double radius = 0;
+    for (int it = 0; it < 16; ++it) {
+        uint32_t far = members[0];
+        double far_reach = -1.0;
+        for (uint32_t i : members) {
+            const double d = reach(i);
+            if (d > far_reach) { far_reach = d; far = i; }
+        }
+        radius = far_reach;
+        const double step = 0.5 / (it + 2.0);
+        for (int a = 0; a < 3; ++a) c[a] += (items[far].c[a] - c[a]) * step;
+    }
+    double last = 0;
+    for (uint32_t i : members) last = std::max(last, reach(i));
+    radius = std::min(radius, last);
+    return radius * radius;
+}
+void improve_partition(const std::vector<Ball>& items, std::vector<std::vector<uint32_t>>& bins, size_t capacity) {
+    const size_t k = bins.size();
+    if (k < 2) return;
+    for (const Ball& b : items)
+        if (!(b.r < 1e15)) return; // an unbounded item: nothing to minimise
+    const size_t NEIGHBOURS = 6, CANDIDATES = 3, PARTNERS = 4;
+    std::vector<double> r2(k);
+    std::vector<std::array<double, 3>> centre(k);
+    auto refresh = [&](size_t j) {
+        r2[j] = bin_radius2(items, bins[j]);
+        std::array<double, 3> c = {0, 0, 0};
+        for (uint32_t i : bins[j])
+            for (int a = 0; a < 3; ++a) c[a] += items[i].c[a];
+        for (int a = 0; a < 3; ++a) c[a] /= (double)std::max<size_t>(1, bins[j].size());
+        centre[j] = c;
+    };
+    for (size_t j = 0; j < k; ++j) refresh(j);
+    // the members of a bin that reach farthest from its centroid, at most `count`: the ones worth handing over
+    auto outermost = [&](size_t j, size_t count) {
+        std::vector<std::pair<double, uint32_t>> by_reach;
+        for (uint32_t i : bins[j]) {
+            double d2 = 0;
+            for (int a = 0; a < 3; ++a) d2 += (items[i].c[a] - centre[j][a]) * (items[i].c[a] - centre[j][a]);
+            by_reach.push_back({-(std::sqrt(d2) + items[i].r), i});
+        }
+        std::sort(by_reach.begin(), by_reach.end());
+        std::vector<uint32_t> out;
+        for (size_t n = 0; n < by_reach.size() && n < count; ++n) out.push_back(by_reach[n].second);
+        return out;
+    };
+    auto without = [](std::vector<uint32_t> v, uint32_t i) {
+        v.erase(std::find(v.begin(), v.end(), i));
+        return v;
+    };
+    for (int pass = 0; pass < 8; ++pass) {
+        bool improved = false;
+        for (size_t a = 0; a < k; ++a) {
+            if (bins[a].size() < 2) continue;
+            for (uint32_t i : outermost(a, CANDIDATES)) {
+                // the bins nearest to item i
+                std::vector<std::pair<double, size_t>> near;
+                for (size_t b = 0; b < k; ++b) {
+                    if (b == a || bins[b].empty()) continue;
+                    double d2 = 0;
+                    for (int x = 0; x < 3; ++x) d2 += (items[i].c[x] - centre[b][x]) * (items[i].c[x] - centre[b][x]);
+                    near.push_back({d2, b});
+                }
+                std::sort(near.begin(), near.end());
+                double best_gain = 1e-9 * (r2[a] + 1.0);
+                size_t best_b = k;
+                std::vector<uint32_t> best_a_members, best_b_members;
+                const std::vector<uint32_t> a_less = without(bins[a], i);
+                for (size_t n = 0; n < near.size() && n < NEIGHBOURS; ++n) {
+                    const size_t b = near[n].second;
+                    const double before = r2[a] + r2[b];
+                    if (bins[b].size() < capacity) {
+                        std::vector<uint32_t> b_more = bins[b];
+                        b_more.push_back(i);
+                        const double gain = before - (bin_radius2(items, a_less) + bin_radius2(items, b_more));
+                        if (gain > best_gain) { best_gain = gain; best_b = b; best_a_members = a_less; best_b_members = b_more; }
+                    }
+                    for (uint32_t j : outermost(b, PARTNERS)) {
+                        std::vector<uint32_t> a_new = a_less, b_new = without(bins[b], j);
+                        a_new.push_back(j);
+                        b_new.push_back(i);
+                        const double gain = before - (bin_radius2(items, a_new) + bin_radius2(items, b_new));
+                        if (gain > best_gain) { best_gain = gain; best_b = b; best_a_members = a_new; best_b_members = b_new; }
+                    }
+                }
+                if (best_b == k) continue;
+                bins[a] = best_a_members;
+                bins[best_b] = best_b_members;
+                refresh(a);
+                refresh(best_b);
+                improved = true;
+                break; // bin a changed: its candidates are stale
+            }
+        }
+        if (!improved) break;
+    }
 }
 
 // Bounding sphere of a cluster: centre by a few "move towards the farthest member" steps, radius =
@@ -505,6 +628,11 @@ std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vect
     std::vector<std::vector<uint32_t>> groups;
     split_groups(bounds, idx, groups, G);
     refine_groups(bounds, groups, G);
+    {
+        std::vector<Ball> balls;
+        for (const RlF4& b : bounds) balls.push_back(Ball{{b.x, b.y, b.z}, bound_radius(b)});
+        improve_partition(balls, groups, G);
+    }
     std::vector<uint32_t> order;
     for (std::vector<uint32_t>& g : groups) {
         std::sort(g.begin(), g.end());
@@ -512,6 +640,135 @@ std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vect
     }
     *groups_out = groups;
     return order;
+}
+
+// ---- choosing the cluster size and the group size of a scene --------------------------------------------------------
+// How well a median-cut partition fits depends on how the scene's sphere count and layout divide (built-in scene: the
+// clusters a ray reaches are 1.6 at 14 per cluster, 2.3 at 12, 1.7 at 10), and so does the trade between fewer, wider
+// groups and more, tighter ones.  So rl_flatten_scene builds the table for every size in RL_CLUSTER_K_CHOICES x {3, 4}
+// clusters per group and keeps the one that costs the kernel least, estimated from the rays of a few hundred sample paths
+// with the kernel's measured cost per step (plan_cost).  Which table is chosen never changes a result.
+struct ClusterPlan {
+    uint32_t k, group_gc;
+    std::vector<std::vector<uint32_t>> clusters; // in table order, short groups filled with empty clusters
+    std::vector<RlF4> cluster_bounds, group_bounds; // {centre, radius^2}; an empty cluster's bound has radius^2 = -inf
+    double cost;
+};
+
+// Second level for one candidate: clusters whose bounds are neighbours become consecutive, group_gc per group; a short group is
+// filled up with never-reached dummy clusters so that a cluster's number is also its position in the cull table.
+ClusterPlan plan_clusters(const std::vector<SphereIn>& sph, const std::vector<std::vector<uint32_t>>& clusters, uint32_t k, uint32_t group_gc) {
+    ClusterPlan plan;
+    plan.k = k;
+    plan.group_gc = group_gc;
+    plan.cost = 0;
+    std::vector<RlF4> bounds;
+    for (const std::vector<uint32_t>& members : clusters) bounds.push_back(cluster_bound(sph, members));
+    std::vector<std::vector<uint32_t>> groups;
+    order_by_groups(bounds, &groups, group_gc);
+    const RlF4 never = RlF4{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()};
+    for (const std::vector<uint32_t>& g : groups) {
+        std::vector<RlF4> members;
+        std::vector<uint32_t> all(g.size());
+        for (uint32_t k2 : g) {
+            plan.clusters.push_back(clusters[k2]);
+            plan.cluster_bounds.push_back(bounds[k2]);
+            members.push_back(bounds[k2]);
+        }
+        std::iota(all.begin(), all.end(), 0u);
+        plan.group_bounds.push_back(group_bound(members, all));
+        for (size_t pad = g.size(); pad < group_gc; ++pad) {
+            plan.clusters.push_back(std::vector<uint32_t>());
+            plan.cluster_bounds.push_back(never);
+        }
+    }
+    return plan;
+}
+
+// Sample rays for plan_cost: the segments of a few hundred paths of THIS scene, traced here with the per-path header the
+// kernel is compiled from (every sphere on the direct list, no table yet), {origin.xyz, far}, {direction.xyz, 0} with
+// far = the ray parameter of the nearest plane / circle / paraboloid hit -- what the kernel's cull knows when it starts on
+// the spheres.  Rays made up from the geometry alone (surface points, uniform directions) rank the plans of the
+// 513-object scene wrongly: where the paths go depends on the materials.  Planning input only: nothing of this reaches
+// a result, every photon comes from the trace kernel.
+std::vector<RlF4> sample_path_rays(const RlFlatScene& fs, const std::vector<SphereIn>& sph) {
+    std::vector<RlF4> spheres, objects = fs.objects;
+    std::vector<uint32_t> sphere_obj;
+    for (const SphereIn& si : sph) {
+        objects[2 * si.obj].y = rl_u2f((uint32_t)spheres.size());
+        spheres.push_back(si.rec);
+        sphere_obj.push_back(si.obj);
+    }
+    RlSceneView sv;
+    std::memset(&sv, 0, sizeof sv);
+    sv.spheres = spheres.data();
+    sv.sphere_obj = sphere_obj.data();
+    sv.objects = objects.data();
+    sv.planes = fs.planes.data();
+    sv.parabs = fs.parabs.data();
+    sv.prisms = fs.prisms.data();
+    sv.n_direct = sv.n_direct_padded = sv.cluster_base = (uint32_t)spheres.size();
+    sv.n_planes = (uint32_t)(fs.planes.size() / 2);
+    sv.n_parabs = (uint32_t)(fs.parabs.size() / 3);
+    sv.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
+    sv.n_objects = (uint32_t)(objects.size() / 2);
+    sv.camera_rec = fs.camera_rec.data();
+    RlSceneView flat_things = sv; // planes, circles, paraboloids only
+    flat_things.n_direct = 0;
+    flat_things.n_prisms = 0;
+    std::vector<RlF4> rays;
+    const uint64_t seed = 0x706c616e6e696e67ull;
+    for (uint64_t path = 0; path < 384 && rays.size() < 2 * 2048; ++path) {
+        RlPath p;
+        rl_begin_path(sv, 16.0f / 9.0f, seed, 0u, path, &p);
+        for (int bounce = 0; bounce < 64; ++bounce) {
+            const RlHit nearest_flat = rl_scan(flat_things, p.origin, p.direction);
+            rays.push_back(RlF4{p.origin.x, p.origin.y, p.origin.z, nearest_flat.t * 1.0002f});
+            rays.push_back(RlF4{p.direction.x, p.direction.y, p.direction.z, 0.0f});
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            float value = 0.0f;
+            uint32_t emitter = 0;
+            if (rl_bounce(sv, seed, 0u, path, &p, hit, &value, &emitter) != RL_PATH_CONTINUES) break;
+        }
+    }
+    return rays;
+}
+
+// Estimated time of the kernel's sphere pass per ray with this plan, in picoseconds of a whole MI355X: every ray tests
+// every group bound (wave-uniform); a (group, ray) pair that passes costs its share of a ring-S round (9 cross-lane
+// fetches, then `group_gc` tests + compactions), a (cluster, ray) pair its share of a ring-A round (the fetches, then
+// a test per member and two or three push steps).  The coefficients are a least-squares fit of the measured throughput
+// of the built-in and the 513-object scene over cluster sizes 8 .. 16 x groups of 3 / 4 (20 builds, residual 0.14 ps
+// against a spread of 0.65 ps) -- in instructions per 64 rays: 28 per group, 100 + 40 per
+// cluster beyond three for a group pair, 12 + 19 per member for a cluster pair.  The exact sphere tests that follow
+// depend on the spheres, not on the plan.
+double plan_cost(const ClusterPlan& plan, const std::vector<RlF4>& rays) {
+    // the segment [0, far] of the ray comes within the bound (the kernel's test without its rounding slack)
+    auto reaches = [](const RlF4& b, const RlF4& o, const RlF4& d) {
+        if (!(b.w > 0.0f)) return false;
+        const double cx = (double)b.x - o.x, cy = (double)b.y - o.y, cz = (double)b.z - o.z;
+        const double d2 = (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z;
+        const double along = std::min(std::max(0.0, (cx * d.x + cy * d.y + cz * d.z) / d2), (double)o.w);
+        const double px = cx - along * d.x, py = cy - along * d.y, pz = cz - along * d.z;
+        return px * px + py * py + pz * pz <= (double)b.w;
+    };
+    const double n_rays = (double)(rays.size() / 2);
+    double group_pairs = 0, cluster_pairs = 0;
+    for (size_t r = 0; r + 1 < rays.size(); r += 2) {
+        for (size_t g = 0; g < plan.group_bounds.size(); ++g) {
+            if (!reaches(plan.group_bounds[g], rays[r], rays[r + 1])) continue;
+            group_pairs += 1;
+            for (size_t k = plan.group_gc * g; k < plan.group_gc * (g + 1); ++k)
+                if (reaches(plan.cluster_bounds[k], rays[r], rays[r + 1])) cluster_pairs += 1;
+        }
+    }
+    const double cost = 0.59 * (double)plan.group_bounds.size() + group_pairs / n_rays * (2.13 + 0.83 * ((double)plan.group_gc - 3.0)) +
+                        cluster_pairs / n_rays * (0.25 + 0.40 * plan.k);
+#ifdef RL_PLAN_DEBUG
+    std::fprintf(stderr, "plan: %u per cluster, %u per group: %zu groups, %.2f group pairs and %.2f cluster pairs per sample ray, cost %.2f\n", plan.k,
+                 plan.group_gc, plan.group_bounds.size(), group_pairs / n_rays, cluster_pairs / n_rays, cost);
+#endif
+    return cost;
 }
 
 } // namespace
@@ -625,7 +882,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
             std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
             median = radii[radii.size() / 2];
         }
-        const bool use_clusters = sph_in.size() >= 4 * RL_CLUSTER_K;
+        const bool use_clusters = sph_in.size() >= 40;
         for (uint32_t k = 0; k < sph_in.size(); ++k) {
             if (!use_clusters || sph_in[k].radius > 4.0 * median || !std::isfinite(sph_in[k].radius)) direct.push_back(k);
             else clustered.push_back(k);
@@ -646,31 +903,50 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     fs.spheres.resize(fs.n_direct_padded + 4, dummy);
     fs.sphere_obj.resize(fs.spheres.size(), RL_HIT_NONE);
     fs.cluster_base = (uint32_t)fs.spheres.size();
-    std::vector<std::vector<uint32_t>> clusters;
-    split_clusters(sph_in, clustered, clusters);
-    refine_clusters(sph_in, clusters);
-    fs.group_gc = clusters.size() > RL_GROUP_GC_MANY ? 4u : 3u;
-    // Second level: clusters whose bounds are neighbours become consecutive, group_gc per group; a short group is
-    // filled up with never-reached dummy clusters so that a cluster's number is also its position in the cull table.
-    const RlF4 never = dummy; // as a bound {c, R^2 = -inf}: fails every cull test, host and device
-    {
-        std::vector<RlF4> bounds;
-        for (std::vector<uint32_t>& members : clusters) bounds.push_back(cluster_bound(sph_in, members));
-        std::vector<std::vector<uint32_t>> groups;
-        order_by_groups(bounds, &groups, fs.group_gc);
-        std::vector<std::vector<uint32_t>> padded;
-        for (const std::vector<uint32_t>& g : groups) {
-            for (uint32_t k : g) padded.push_back(clusters[k]);
-            for (size_t pad = g.size(); pad < fs.group_gc; ++pad) padded.push_back(std::vector<uint32_t>());
+    // Cluster size and group size: the plan with the lowest estimated cost per ray (plan_clusters, plan_cost).
+    ClusterPlan plan;
+    plan.k = 10;
+    plan.group_gc = 3;
+    if (!clustered.empty()) {
+#ifdef RL_CLUSTER_K
+        static_assert(RL_CLUSTER_K >= 2 && RL_CLUSTER_K <= RL_CLUSTER_K_MAX, "cluster size out of range");
+        const std::vector<uint32_t> sizes = {RL_CLUSTER_K};
+#else
+        const std::vector<uint32_t> sizes = RL_CLUSTER_K_CHOICES;
+#endif
+        const std::vector<RlF4> rays = sample_path_rays(fs, sph_in);
+        bool first = true;
+        for (uint32_t k : sizes) {
+            std::vector<std::vector<uint32_t>> clusters;
+            split_clusters(sph_in, clustered, clusters, k);
+            refine_clusters(sph_in, clusters, k);
+            {
+                std::vector<Ball> balls;
+                for (const SphereIn& si : sph_in) balls.push_back(Ball{{si.rec.x, si.rec.y, si.rec.z}, si.radius});
+                improve_partition(balls, clusters, k);
+            }
+#ifdef RL_GROUP_GC
+            for (uint32_t g : {(uint32_t)RL_GROUP_GC}) {
+#else
+            for (uint32_t g : {3u, 4u}) {
+#endif
+                ClusterPlan candidate = plan_clusters(sph_in, clusters, k, g);
+                candidate.cost = plan_cost(candidate, rays);
+                if (first || candidate.cost < plan.cost) plan = candidate;
+                first = false;
+            }
         }
-        clusters = padded;
     }
+    fs.cluster_k = plan.k;
+    fs.group_gc = plan.group_gc;
+    const RlF4 never = dummy; // as a bound {c, R^2 = -inf}: fails every cull test, host and device
+    std::vector<std::vector<uint32_t>>& clusters = plan.clusters;
     for (std::vector<uint32_t>& members : clusters) {
         std::sort(members.begin(), members.end()); // ascending object order inside a cluster
         fs.spheres.push_back(members.empty() ? never : cluster_bound(sph_in, members));
         fs.sphere_obj.push_back(RL_HIT_NONE);
         for (uint32_t k : members) place(k);
-        for (size_t pad = members.size(); pad < RL_CLUSTER_K; ++pad) {
+        for (size_t pad = members.size(); pad < fs.cluster_k; ++pad) {
             fs.spheres.push_back(dummy);
             fs.sphere_obj.push_back(RL_HIT_NONE);
         }
@@ -726,7 +1002,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         if (std::isfinite(b.w)) fs.cull_cmax2 = std::max(fs.cull_cmax2, (float)c2 * 1.0001f);
     };
     std::vector<RlF4> level1;
-    for (uint32_t k = 0; k < fs.n_clusters; ++k) level1.push_back(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
+    for (uint32_t k = 0; k < fs.n_clusters; ++k) level1.push_back(fs.spheres[fs.cluster_base + (fs.cluster_k + 1u) * k]);
     for (uint32_t i = 0; i < n_prisms; ++i) level1.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
     for (const RlF4& b : level1) add_bound(b);
     const size_t n_cluster_level1 = (size_t)fs.group_gc * fs.n_cluster_groups;

@@ -6,7 +6,7 @@
 // 16-byte fetch (LDS broadcast or scalar load):
 //
 //   spheres   1 x RlF4 each : {centre.xyz, radius^2}                         geometry.rs:186-200
-//             "direct" spheres first (tested by every ray), then clusters of RL_CLUSTER_K spatially
+//             "direct" spheres first (tested by every ray), then clusters of cluster_k spatially
 //             close spheres, each preceded by a {bounding-sphere centre, radius^2} record (on the DEVICE a clustered
 //             sphere's record is {centre.xyz, |centre|^2 - 1.001 radius^2}, see RlSceneView::sphere_r2)
 //   planes    2 x RlF4 each : {normal.xyz, radius^2 or -1}, {offset.xyz, obj} geometry.rs:35-51,130-150
@@ -42,16 +42,13 @@ struct alignas(16) RlF4 {
 };
 
 #define RL_PRISM_STRIDE 17 // records per hexagonal prism: 16 half-space records + 1 bound
-#ifndef RL_CLUSTER_K
-#define RL_CLUSTER_K 10                        // spheres per cluster (tuned on MI355X: DESIGN.md)
-#endif
-#define RL_CLUSTER_STRIDE (RL_CLUSTER_K + 1)   // + the bound record in front (odd stride: LDS banks)
-// Bounds per second-level group of the cull table, tuned on MI355X.  Clusters: threes up to 40 clusters, fours
-// beyond (RlFlatScene::group_gc: the 513-object scene, 49 clusters, gains 3 % with fours; the built-in one, 32, loses 0.3 %).
-// Prisms: threes (the glass-stress scene loses 2.5 % with fours).
-#ifndef RL_GROUP_GC_MANY
-#define RL_GROUP_GC_MANY 40
-#endif
+// Spheres per cluster: chosen per scene (RlFlatScene::cluster_k, rl_scene.cpp) among RL_CLUSTER_K_CHOICES.  A cluster
+// takes cluster_k + 1 records: the bound in front.  -DRL_CLUSTER_K=n forces one size (A/B builds; at most
+// RL_CLUSTER_K_MAX: the kernel keeps one bit per member in a 32-bit mask).
+#define RL_CLUSTER_K_MAX 31
+#define RL_CLUSTER_K_CHOICES {10, 14} // (the kernel's member loop is unrolled for exactly these)
+// Bounds per second-level group of the cull table.  Clusters: 3 or 4, chosen per scene together with the cluster size
+// (RlFlatScene::group_gc; -DRL_GROUP_GC=n forces one).  Prisms: threes (the glass-stress scene loses 2.5 % with fours).
 #ifndef RL_GROUP_GP
 #define RL_GROUP_GP 3
 #endif
@@ -74,7 +71,8 @@ struct RlSceneView {
     uint32_t n_direct;         // direct spheres: records [0, n_direct)
     uint32_t n_direct_padded;  // multiple of 4; records [n_direct, n_direct_padded + 4) are dummies
     uint32_t cluster_base;     // first cluster record (= n_direct_padded + 4)
-    uint32_t n_clusters;       // each RL_CLUSTER_STRIDE records: bound, then RL_CLUSTER_K spheres
+    uint32_t n_clusters;       // each cluster_k + 1 records: bound, then cluster_k spheres
+    uint32_t cluster_k;
     // 3 records: the 10 floats of RlCameraDesc, then screen_distance = 1 / tan(field_of_view / 2)
     // (camera.rs:56, constant per scene).  Read from memory where a path starts instead of being held
     // in a dozen scalar registers across the whole persistent loop.
@@ -93,13 +91,13 @@ struct RlFlatScene {
     // group's members.  Not in the reference; conservative like the bounds themselves.
     std::vector<RlF4> cull_bounds;
     uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [group_gc * n_cluster_groups][GP * n_prism_groups][groups][groups][slack]
-    uint32_t group_gc = 3;                     // clusters per group (3 or 4, see RL_GROUP_GC_MANY)
+    uint32_t group_gc = 3;                     // clusters per group (3 or 4), chosen with cluster_k: rl_scene.cpp, plan_cost
     std::vector<RlF4> prism_cyl;               // 2 records per prism {point on the axis, radius}, {unit axis, 0}; empty unless
     bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
-    uint32_t n_direct, n_direct_padded, cluster_base, n_clusters; // see RlSceneView
+    uint32_t n_direct, n_direct_padded, cluster_base, n_clusters, cluster_k; // see RlSceneView
     RlCameraDesc camera;
     float screen_distance;
     std::vector<RlF4> camera_rec; // see RlSceneView

@@ -29,6 +29,7 @@ def lib():
         L.mirror_prism_fast_check_paths.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
         L.mirror_prism_cylinders.restype = u32
         L.mirror_prism_cylinders.argtypes = [vp, vp, u32]
+        L.mirror_cull_counts.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
         L.mirror_prism_pairs.restype = u64
         L.mirror_prism_pairs.argtypes = [vp, u64, u64, vp, vp, vp, u64]
         _lib = L
@@ -98,3 +99,13 @@ def plot(w, h, photons):
     photons = np.ascontiguousarray(photons)
     lib().mirror_plot(O.ptr(buffer), w, h, O.ptr(photons), len(photons))
     return buffer
+
+
+def cull_counts(scene, w, h, seed, stream, first, n):
+    """What the kernel's sphere pass does with `scene`'s cull table on the segments of paths [first, first + n), counted on
+    the host: per segment the (group, ray), (cluster, ray) and (member, ray) pairs that pass, and the table's shape."""
+    c = np.zeros(8, dtype=np.uint64)
+    lib().mirror_cull_counts(scene.h, w, h, seed, stream, first, n, O.ptr(c))
+    seg = float(c[0])
+    return {"segments": int(c[0]), "groups": int(c[1]), "group_pairs": float(c[2]) / seg, "cluster_pairs": float(c[3]) / seg,
+            "member_pairs": float(c[4]) / seg, "clusters": int(c[5]), "clusters_per_group": int(c[6]), "members_per_cluster": int(c[7])}

@@ -40,6 +40,7 @@ void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDe
     v.n_direct_padded = m->flat.n_direct_padded;
     v.cluster_base = m->flat.cluster_base;
     v.n_clusters = m->flat.n_clusters;
+    v.cluster_k = m->flat.cluster_k;
     v.n_planes = (uint32_t)(m->flat.planes.size() / 2);
     v.n_parabs = (uint32_t)(m->flat.parabs.size() / 3);
     v.n_prisms = (uint32_t)(m->flat.prisms.size() / RL_PRISM_STRIDE);
@@ -135,7 +136,7 @@ extern "C" uint32_t mirror_bounds(void* scene, float* out4, uint32_t cap, uint32
         }
         n++;
     };
-    for (uint32_t k = 0; k < fs.n_clusters; ++k) put(fs.spheres[fs.cluster_base + RL_CLUSTER_STRIDE * k]);
+    for (uint32_t k = 0; k < fs.n_clusters; ++k) put(fs.spheres[fs.cluster_base + (fs.cluster_k + 1u) * k]);
     if (n_clusters) *n_clusters = fs.n_clusters;
     for (size_t i = 0; i < fs.prisms.size() / RL_PRISM_STRIDE; ++i) put(fs.prisms[RL_PRISM_STRIDE * i + 16]);
     return n;
@@ -345,4 +346,67 @@ extern "C" uint32_t mirror_prism_cylinders(void* scene, float* out8, uint32_t ca
         o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w; o[4] = a.x; o[5] = a.y; o[6] = a.z; o[7] = 0.0f;
     }
     return n;
+}
+
+// ---- the cull table's work per ray segment, counted on the host ----------------------------------------------------
+// Traces paths [first, first + n) and counts, per segment, what the kernel's sphere pass would do with this scene's table:
+// counts[0] = segments, [1] = cluster groups, [2] = (group, ray) pairs that pass, [3] = (cluster, ray) pairs that pass,
+// [4] = (member, ray) pairs that pass, [5] = clusters, [6] = clusters per group, [7] = members per cluster.  Bounds are
+// tested as the kernel does (reach the bound ahead of the origin and not beyond `far`, the nearest plane / circle /
+// paraboloid hit), without its rounding slack: a planning figure for tools and tests, not a parity statement.
+static bool mirror_reach(RlF4 b, RlF3 o, RlF3 dir, double far_t) {
+    const double cox = (double)b.x - o.x, coy = (double)b.y - o.y, coz = (double)b.z - o.z;
+    const double d2 = (double)dir.x * dir.x + (double)dir.y * dir.y + (double)dir.z * dir.z;
+    const double dd = (dir.x * cox + dir.y * coy + dir.z * coz) / d2; // ray parameter of the point nearest to the centre
+    double x = dd < 0.0 ? 0.0 : dd;
+    if (x > far_t) x = far_t;
+    const double px = cox - x * dir.x, py = coy - x * dir.y, pz = coz - x * dir.z;
+    return px * px + py * py + pz * pz <= (double)b.w;
+}
+extern "C" void mirror_cull_counts(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first, uint64_t n,
+                                   uint64_t* counts) {
+    const MirrorScene* ms = (MirrorScene*)scene;
+    const RlSceneView& sv = ms->view;
+    const RlFlatScene& fs = ms->flat;
+    const float aspect = (float)w / (float)h;
+    for (int i = 0; i < 8; ++i) counts[i] = 0;
+    counts[1] = fs.n_cluster_groups;
+    counts[5] = fs.n_clusters;
+    counts[6] = fs.group_gc;
+    counts[7] = fs.cluster_k;
+    const uint32_t n_level1 = fs.group_gc * fs.n_cluster_groups + RL_GROUP_GP * fs.n_prism_groups;
+    for (uint64_t i = 0; i < n; ++i) {
+        RlPath p;
+        rl_begin_path(sv, aspect, seed, stream, first + i, &p);
+        float value = 0.0f;
+        for (;;) {
+            counts[0] += 1;
+            // far bound: planes, circles, paraboloids only (what the kernel knows before its sphere pass)
+            RlSceneView small = sv;
+            small.n_direct = 0; small.n_clusters = 0; small.n_prisms = 0;
+            const RlHit near = rl_scan(small, p.origin, p.direction);
+            const double far_t = (double)near.t * 1.0002;
+            for (uint32_t g = 0; g < fs.n_cluster_groups; ++g) {
+                const RlF4 r = fs.cull_bounds[n_level1 + g];
+                const double c2 = (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z;
+                RlF4 gb = r;
+                gb.w = (float)(c2 - (double)r.w);
+                if (!mirror_reach(gb, p.origin, p.direction, far_t)) continue;
+                counts[2] += 1;
+                for (uint32_t k = fs.group_gc * g; k < fs.group_gc * (g + 1); ++k) {
+                    const uint32_t base = sv.cluster_base + (fs.cluster_k + 1u) * k;
+                    if (!mirror_reach(sv.spheres[base], p.origin, p.direction, far_t)) continue;
+                    counts[3] += 1;
+                    for (uint32_t j = 1; j <= fs.cluster_k; ++j) {
+                        RlF4 s = sv.spheres[base + j];
+                        s.w *= 1.001f;
+                        if (s.w > 0.0f && mirror_reach(s, p.origin, p.direction, far_t)) counts[4] += 1;
+                    }
+                }
+            }
+            const RlHit hit = rl_scan(sv, p.origin, p.direction);
+            uint32_t emitter = 0;
+            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value, &emitter) != RL_PATH_CONTINUES) break;
+        }
+    }
 }

@@ -159,9 +159,26 @@ def test_cull_table_is_conservative_by_construction():
             big = radii > 4 * np.median(radii)                     # the direct list
             assert inside_some[~big].all()
     assert checked > 150
-    # threes up to RL_GROUP_GC_MANY (40) clusters, fours beyond: the built-in scene (32 clusters), its glass variant, the
-    # 513-object scene (49 clusters)
-    assert group_sizes[:3] == [(3, 3), (3, 3), (4, 3)]
+    # every scene gets one of the plans the kernel has an unrolled member loop for
+    assert all(gc in (3, 4) and gp == 3 for gc, gp in group_sizes)
+
+
+def test_the_cull_table_is_planned_per_scene():
+    """rl_flatten_scene builds the table for each cluster size the kernel has an unrolled member loop for x 3 / 4 clusters per
+    group and keeps the plan its cost estimate likes best (rl_scene.cpp: plan_cost over the rays of sample paths).  The
+    choices below are the ones that measured fastest on MI355X; what a plan changes is how many bounds
+    a ray is tested against -- never a result (the bit-exact tests in this file run on whatever plan was chosen)."""
+    demo = M.cull_counts(M.Scene(*M.builtin_desc(0, 0)), 1920, 1080, 42, 0, 0, 3000)
+    replicated = M.cull_counts(M.Scene(*M.builtin_desc(0, 158)), 1920, 1080, 42, 0, 0, 3000)
+    assert demo["members_per_cluster"] == 14 and demo["clusters_per_group"] in (3, 4)
+    assert replicated["members_per_cluster"] == 10 and replicated["clusters_per_group"] == 4
+    # the quantities the plan is about: a ray of the built-in scene reaches ~1.7 groups and ~1.6 clusters, 0.55 members pass
+    assert 1.4 < demo["group_pairs"] < 2.0 and 1.4 < demo["cluster_pairs"] < 1.8 and 0.4 < demo["member_pairs"] < 0.7
+    assert replicated["cluster_pairs"] < 2.6
+    # a scene too small for clusters has no table at all
+    objs, cam = M.builtin_desc(0, 0)
+    few = M.cull_counts(M.Scene(objs[objs["surface_kind"] != 0][:30], cam), 640, 360, 1, 0, 0, 100)
+    assert few["clusters"] == 0 and few["group_pairs"] == 0
 
 
 # ---- the prism shortcut (rl_hex_prism_fast) against the Compound tree it stands in for (geometry.rs:380-407) ----------
