@@ -213,6 +213,15 @@ __device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, 
 //   with x = clamp(D.co, 0, far) -- the point of the segment [0, far] nearest to the bound's centre -- f(x) <= 0 says that
 //   the segment reaches the bound: for x = D.co it is the discriminant test above, for x = 0 "the origin is inside",
 //   for x = far "the entry point is not beyond the hit".  One v_med3 and one FMA more than the test without `far`.
+// rl_cull_margin() >= 0 <=> the bound passes (rl_cull_pass); its sign bit is set exactly where the test fails (x - x is +0, and
+// no operand is a NaN where a result is used: a lane beyond its round has q = -inf, a never-reached record w = +inf, and
+// -inf - inf = -inf).
+__device__ __forceinline__ float rl_cull_margin(const RlCullRay& r, RlF4 b, float far) {
+    const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
+    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
+    const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
+    return r.q - __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs);
+}
 __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b, float far) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
@@ -433,8 +442,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         float r_far;
         rl_fetch_cull_ray(owner, cr, far, r, r_far);
         if (lane >= count) r.q = -__builtin_inff(); // lanes beyond the round never push
-        // The members that pass are collected as one bit per member in a lane-private mask (one v_addc per member: shift
-        // left, carry in the compare mask) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
+        // The members that pass are collected as one bit per member in a lane-private mask (one v_alignbit per member: shift
+        // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
         // per pair, so two or three steps replace ten ballot / count / write sequences.
         uint32_t passed = 0;
         const uint32_t n_members = sv.cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
@@ -443,13 +452,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #define RL_MEMBERS(N)                                                                                                    \
         {                                                                                                                \
             RlF4 mb = sph[first];                                                                                        \
+            uint32_t failed = 0; /* one bit per member: the sign of the test's margin, shifted in with one v_alignbit */  \
             for (uint32_t j = 0; j < (N); ++j) {                                                                         \
                 const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
-                const uint64_t m = __builtin_amdgcn_ballot_w64(rl_cull_pass(r, mb, r_far));                              \
-                uint64_t carry_out;                                                                                      \
-                asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(passed), "=s"(carry_out) : "s"(m)); /* member j ends up at bit N - 1 - j */ \
+                failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
             }                                                                                                            \
+            passed = ~failed & ((1u << (N)) - 1u);                                                                       \
         }
         if (n_members == 10u) RL_MEMBERS(10u)
         else if (n_members == 14u) RL_MEMBERS(14u)

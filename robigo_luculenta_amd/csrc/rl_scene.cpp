@@ -932,7 +932,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
 #endif
                 ClusterPlan candidate = plan_clusters(sph_in, clusters, k, g);
                 candidate.cost = plan_cost(candidate, rays);
-                if (first || candidate.cost < plan.cost) plan = candidate;
+                if (first || candidate.cost < plan.cost * 0.995) plan = candidate; // (a later, larger plan has to win by more than the estimate's noise)
                 first = false;
             }
         }
