@@ -381,6 +381,42 @@ def test_random_scenes_bit_exact_on_device(seed):
         assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
 
 
+@pytest.mark.parametrize("layout", ["same", "line", "zero_radius", "huge_spread", "infinite"])
+def test_degenerate_sphere_layouts_through_the_planned_table_on_device(layout):
+    """The cull table is planned per scene (rl_scene.cpp: cluster size 10 or 14, 3 or 4 clusters per group, local search, cost
+    estimate over sample paths); here it gets sphere sets it cannot do anything sensible with, at the sizes where clusters
+    start and where groups fill unevenly.  The photons must equal the oracle's linear scan bit for bit in both fetch modes."""
+    objs0, cam = R.builtin_scene_desc(R.SCENE_DEMO)
+    proto = objs0[objs0["surface_kind"] == 0][:1]
+    rest = objs0[objs0["surface_kind"] != 0]
+    rng = np.random.default_rng(7)
+    N = 1 << 14
+    for n in (40, 41, 57, 141):
+        o = np.repeat(proto, n)
+        o["v0"] = rng.normal(0, 8, (n, 3)).astype(np.float32)
+        o["v0"][:, 1] = np.abs(o["v0"][:, 1])
+        o["f"][:, 0] = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        if layout == "same":
+            o["v0"] = np.array([1.0, 2.0, 3.0], np.float32)
+        elif layout == "line":
+            o["v0"] = np.stack([np.linspace(-20, 20, n), np.ones(n), np.ones(n)], 1).astype(np.float32)
+        elif layout == "zero_radius":
+            o["f"][:, 0] = 0.0
+        elif layout == "huge_spread":
+            o["v0"] = (rng.normal(0, 1, (n, 3)) * np.exp(rng.uniform(-5, 12, (n, 1)))).astype(np.float32)
+            o["f"][:, 0] = np.exp(rng.uniform(-8, 3, n)).astype(np.float32)
+        elif layout == "infinite":
+            o["f"][0, 0] = np.inf
+        objs = np.concatenate([rest, o])
+        want, segs = O.Scene(objs, _ocam(cam)).render(320, 180, 3, 0, 0, N, threads=8)
+        scene = R.Scene(objs, cam)
+        for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+            t = R.TraceUnit(0, 320, 180, n_photons=N)
+            t.set_fetch(fetch)
+            t.render(scene, seed=3, stream=0, first_path_index=0)
+            assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs, (layout, n, fetch)
+
+
 @pytest.mark.parametrize("seed", [21, 22, 23])
 def test_random_scenes_with_many_prisms_use_the_second_bound_and_stay_bit_exact(seed):
     """From 40 prisms on the kernel tests a cylinder around every prism's axis besides its bounding sphere (the CYL

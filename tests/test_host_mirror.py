@@ -181,6 +181,40 @@ def test_the_cull_table_is_planned_per_scene():
     assert few["clusters"] == 0 and few["group_pairs"] == 0
 
 
+@pytest.mark.parametrize("layout", ["same", "line", "zero_radius", "huge_spread", "infinite", "random"])
+def test_planned_table_on_degenerate_sphere_layouts(layout):
+    """The planner (median cuts, k-means, local search, sample paths, cost estimate) gets sphere sets it cannot do anything
+    sensible with -- all at one point, on a line, of radius zero, spread over seven decades, one of infinite radius -- at the
+    sizes where clusters start (40 spheres) and where groups fill unevenly: it must terminate, and the paths through the
+    table it built must equal the oracle's linear scan bit for bit."""
+    objs0, cam = M.builtin_desc(0, 0)
+    proto = objs0[objs0["surface_kind"] == 0][:1]
+    rest = objs0[objs0["surface_kind"] != 0]
+    rng = np.random.default_rng(7)
+    for n in (40, 41, 57, 141):
+        o = np.repeat(proto, n)
+        o["v0"] = rng.normal(0, 8, (n, 3)).astype(np.float32)
+        o["v0"][:, 1] = np.abs(o["v0"][:, 1])
+        o["f"][:, 0] = rng.uniform(0.1, 1.0, n).astype(np.float32)
+        if layout == "same":
+            o["v0"] = np.array([1.0, 2.0, 3.0], np.float32)
+        elif layout == "line":
+            o["v0"] = np.stack([np.linspace(-20, 20, n), np.ones(n), np.ones(n)], 1).astype(np.float32)
+        elif layout == "zero_radius":
+            o["f"][:, 0] = 0.0
+        elif layout == "huge_spread":
+            o["v0"] = (rng.normal(0, 1, (n, 3)) * np.exp(rng.uniform(-5, 12, (n, 1)))).astype(np.float32)
+            o["f"][:, 0] = np.exp(rng.uniform(-8, 3, n)).astype(np.float32)
+        elif layout == "infinite":
+            o["f"][0, 0] = np.inf
+        scene = np.concatenate([rest, o])
+        so, sm = O.Scene(scene, cam), M.Scene(scene, cam)
+        want, segs = so.render(320, 180, 3, 0, 0, 6000, threads=8)
+        got, segs2 = sm.render(320, 180, 3, 0, 0, 6000)
+        assert segs == segs2 and got.tobytes() == want.tobytes(), (layout, n)
+        assert M.cull_counts(sm, 320, 180, 3, 0, 0, 200)["members_per_cluster"] in (10, 14)
+
+
 # ---- the prism shortcut (rl_hex_prism_fast) against the Compound tree it stands in for (geometry.rs:380-407) ----------
 
 @pytest.mark.parametrize("which", [0, 1])
