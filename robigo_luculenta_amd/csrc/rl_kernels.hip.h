@@ -213,9 +213,9 @@ __device__ __forceinline__ RlCullRay rl_cull_ray(RlF3 o, RlF3 dir, float cmax2, 
 //   with x = clamp(D.co, 0, far) -- the point of the segment [0, far] nearest to the bound's centre -- f(x) <= 0 says that
 //   the segment reaches the bound: for x = D.co it is the discriminant test above, for x = 0 "the origin is inside",
 //   for x = far "the entry point is not beyond the hit".  One v_med3 and one FMA more than the test without `far`.
-// rl_cull_margin() >= 0 <=> the bound passes (rl_cull_pass); its sign bit is set exactly where the test fails (x - x is +0, and
-// no operand is a NaN where a result is used: a lane beyond its round has q = -inf, a never-reached record w = +inf, and
-// -inf - inf = -inf).
+// rl_cull_margin() >= 0 <=> the bound passes (rl_cull_pass); for a ray with a path its sign bit is set exactly where the test
+// fails (x - x is +0; a never-reached record has w = +inf and a margin of -inf).  A ray WITHOUT a path has NaN terms and a
+// margin whose sign says nothing: callers mask such lanes out themselves.
 __device__ __forceinline__ float rl_cull_margin(const RlCullRay& r, RlF4 b, float far) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
@@ -441,7 +441,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RlCullRay r;
         float r_far;
         rl_fetch_cull_ray(owner, cr, far, r, r_far);
-        if (lane >= count) r.q = -__builtin_inff(); // lanes beyond the round never push
         // The members that pass are collected as one bit per member in a lane-private mask (one v_alignbit per member: shift
         // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
         // per pair, so two or three steps replace ten ballot / count / write sequences.
@@ -458,7 +457,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                 failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
             }                                                                                                            \
-            passed = ~failed & ((1u << (N)) - 1u);                                                                       \
+            passed = lane < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
         }
         if (n_members == 10u) RL_MEMBERS(10u)
         else if (n_members == 14u) RL_MEMBERS(14u)
