@@ -299,7 +299,7 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-template <bool CYL>
+template <bool CYL, bool SPLIT>
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
@@ -434,10 +434,17 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_STAT(RL_ST_A_LANES, count);
         RL_T0(t_a);
         rl_wave_sync();
-        const uint32_t e = ring_a[(a_head + lane) & 127u];
+        // SPLIT (the plain launches; the open ones have no registers to spare for it): a round of at most 32 pairs -- 18 % of
+        // them, the flush at the end of the sphere pass -- gives every pair two lanes, each with half of the members: half the
+        // loop for the same round.
+        const uint32_t n_members = sv.cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
+        const bool split = SPLIT && count <= 32u && (n_members == 10u || n_members == 14u);
+        const uint32_t slot = split ? (lane & 31u) : lane;
+        const uint32_t e = ring_a[(a_head + slot) & 127u];
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
-        const uint32_t first = sv.cluster_base + (sv.cluster_k + 1u) * (lane < count ? (e >> 6) : 0u) + 1u;
+        uint32_t first = sv.cluster_base + (sv.cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
+        if (split) first += (lane >> 5) * (n_members >> 1);
         RlCullRay r;
         float r_far;
         rl_fetch_cull_ray(owner, cr, far, r, r_far);
@@ -445,9 +452,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
         // per pair, so two or three steps replace ten ballot / count / write sequences.
         uint32_t passed = 0;
-        const uint32_t n_members = sv.cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
-        // MEMBERS(N): the loop over N members, N a constant where it is one of the sizes rl_scene.cpp chooses from -- unrolled,
-        // the members' addresses are immediates -- and n_members otherwise (a build that forces another size: rolled, ~2 % slower).
+        uint32_t n_mine = n_members; // members this lane tests (wave-uniform)
+        // MEMBERS(N): the loop over N members from `first`, N a constant where the cluster size is one of those rl_scene.cpp chooses
+        // from -- unrolled, the members' addresses are immediates -- and n_members otherwise (a build that forces another size: rolled, ~2 % slower).
 #define RL_MEMBERS(N)                                                                                                    \
         {                                                                                                                \
             RlF4 mb = sph[first];                                                                                        \
@@ -457,15 +464,18 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                 failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
             }                                                                                                            \
-            passed = lane < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
+            passed = slot < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
+            n_mine = (N);                                                                                                \
         }
-        if (n_members == 10u) RL_MEMBERS(10u)
-        else if (n_members == 14u) RL_MEMBERS(14u)
-        else RL_MEMBERS(n_members)
+        if (n_members == 10u) {
+            if (split) RL_MEMBERS(5u) else RL_MEMBERS(10u)
+        } else if (n_members == 14u) {
+            if (split) RL_MEMBERS(7u) else RL_MEMBERS(14u)
+        } else RL_MEMBERS(n_members)
 #undef RL_MEMBERS
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
-            const uint32_t j = (n_members - 1u) - (uint32_t)__builtin_ctz(passed);
+            const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed);
             if (passed != 0u) ring_b[(b_tail + rl_mbcnt(any)) & 127u] = ((first + j) << 6) | owner;
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;
@@ -1023,7 +1033,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
             continue;
         }
-        const RlHit hit = rl_scan_wave<CYL>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL, !OPEN>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
