@@ -310,9 +310,9 @@ InfinitePrism new_infinite_prism(Vector3 axis, Vector3 offset, float edge_length
     float a1 = angle;
     float a2 = angle + PI * 2.0f / 3.0f;
     float a3 = angle + PI * 4.0f / 3.0f;
-    Vector3 p1{rl_cosf(a1), rl_sinf(a1), 0.0f};
-    Vector3 p2{rl_cosf(a2), rl_sinf(a2), 0.0f};
-    Vector3 p3{rl_cosf(a3), rl_sinf(a3), 0.0f};
+    Vector3 p1{rl_cosf_d(a1), rl_sinf_d(a1), 0.0f};
+    Vector3 p2{rl_cosf_d(a2), rl_sinf_d(a2), 0.0f};
+    Vector3 p3{rl_cosf_d(a3), rl_sinf_d(a3), 0.0f};
     p1 = rotate_towards(p1, axis);
     p2 = rotate_towards(p2, axis);
     p3 = rotate_towards(p3, axis);
@@ -623,20 +623,20 @@ std::vector<RlObjectDesc> demo_scene_desc(int seeds_param) {
     for (long i = first_seed; i < first_seed + seeds; ++i) {                        // app.rs:239-253
         float phi = (float)i * gamma;
         float r = sqrtf((float)i) * seed_scale;
-        Vector3 position = Vector3{rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.5f} + sun_position;
+        Vector3 position = Vector3{rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * -0.5f} + sun_position;
         objects.push_back(od(RL_SURFACE_SPHERE, position, Z, seed_size, 0, 0, 0, RL_MATERIAL_DIFFUSE_COLOURED, 0.9f,
                              (float)(i - first_seed) / (float)seeds * 130.0f + 600.0f, 60.0f));
     }
     for (long i = first_seed; i < first_seed + seeds; ++i) {                        // app.rs:256-268
         float phi = ((float)i + 0.5f) * gamma;
         float r = sqrtf((float)i + 0.5f) * seed_scale;
-        Vector3 position = Vector3{rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.25f} + sun_position;
+        Vector3 position = Vector3{rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * -0.25f} + sun_position;
         objects.push_back(od(RL_SURFACE_SPHERE, position, Z, seed_size * 0.5f, 0, 0, 0, RL_MATERIAL_GLOSSY_MIRROR, 0.1f, 0, 0));
     }
     for (long i = first_seed / 2; i < first_seed + seeds; ++i) {                    // app.rs:271-284
         float phi = (float)(-i) * gamma;
         float r = sqrtf((float)i) * seed_scale * 1.5f;
-        Vector3 position = Vector3{rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * 1.5f + sun_radius * 2.0f} + sun_position;
+        Vector3 position = Vector3{rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * 1.5f + sun_radius * 2.0f} + sun_position;
         objects.push_back(od(RL_SURFACE_SPHERE, position, Z, seed_size * (0.5f + sqrtf((float)i) * 0.2f), 0, 0, 0,
                              RL_MATERIAL_SOAP_BUBBLE, 0, 0, 0));
     }
@@ -648,7 +648,7 @@ std::vector<RlObjectDesc> demo_scene_desc(int seeds_param) {
         for (int v = 0; v < 2; ++v) {
             float ofs = variants[v][0], radius = variants[v][1], phi_ofs = variants[v][2], h = variants[v][3];
             float phi = (float)i * prism_angle + ofs;
-            Vector3 position{rl_cosf(phi) * prism_radius * radius, rl_sinf(phi) * prism_radius * radius, 0.0f};
+            Vector3 position{rl_cosf_d(phi) * prism_radius * radius, rl_sinf_d(phi) * prism_radius * radius, 0.0f};
             Vector3 normal{0.0f, 0.0f, -1.0f};
             Ray ray{position, normal, 0.0f, 1.0f};
             OptIsect is = floor_paraboloid.intersect(ray);
@@ -988,7 +988,7 @@ void oracle_rng_block(uint64_t seed, uint32_t stream, uint64_t path, uint32_t bl
     RlRngBlock b = rl_rng_block(seed, stream, path, block);
     memcpy(out, b.w, 16);
 }
-// fn: 0 sin 1 cos 2 tan 3 exp 4 log 5 acos 6 closed01(bits) 7 halfopen01(bits)
+// fn: 0 sin 1 cos 2 tan 3 exp 4 log 5 acos 6 closed01(bits) 7 halfopen01(bits); 8 sin 9 cos 10 exp 11 acos in their f64-evaluated forms
 void oracle_math_f32(int fn, const float* x, float* y, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) {
         switch (fn) {
@@ -1000,6 +1000,10 @@ void oracle_math_f32(int fn, const float* x, float* y, uint64_t n) {
         case 5: y[i] = rl_acosf(x[i]); break;
         case 6: y[i] = rl_closed01(rl_bits_f(x[i])); break;
         case 7: y[i] = rl_halfopen01(rl_bits_f(x[i])); break;
+        case 8: y[i] = rl_sinf_d(x[i]); break;
+        case 9: y[i] = rl_cosf_d(x[i]); break;
+        case 10: y[i] = rl_expf_d(x[i]); break;
+        case 11: y[i] = rl_acosf_d(x[i]); break;
         default: y[i] = 0.0f;
         }
     }

@@ -398,9 +398,17 @@ def batch_histogram(device=0):
     return {k: int(out[k]) for k in range(1, 257) if out[k]}
 
 
+def variant_launches():
+    """rl_debug_variant_launches: launches per instantiation of the trace kernel since the library was loaded;
+    index = 8 * staged in LDS + 4 * fused + 2 * open launch + 1 * prisms with a second bound."""
+    out = (C.c_uint64 * 16)()
+    check(lib.rl_debug_variant_launches(out))
+    return list(out)
+
+
 def math_probe(fn, x, device=0):
     """Evaluates csrc/rl_math.h function `fn` on the GPU (diagnostics for the parity tests)."""
-    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10, "normalise": 11}
+    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10, "normalise": 11, "sin_d": 12, "cos_d": 13, "exp_d": 14, "acos_d": 15}
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.zeros_like(x)
     check(lib.rl_debug_math_probe(device, names[fn], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))

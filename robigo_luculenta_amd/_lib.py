@@ -132,6 +132,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
     "rl_debug_batch_histogram": (_i, [_i, _vp]),
+    "rl_debug_variant_launches": (_i, [_vp]),
     "rl_debug_prism_probe": (_i, [_vp, _u32, _vp, _u32, _vp]),
     "rl_debug_prism_count": (_i, [_vp, C.POINTER(_u32)]),
 }

@@ -188,7 +188,9 @@ int drain_events(RlTraceUnit* u) {
 // the splat or not, an open launch or a plain one, prisms with a second bound or without.
 typedef void (*TraceKernel)(const RlF4*, RlSceneLayout, RlTraceJob, RlMappedPhoton*, float*, unsigned long long*, const RlJobEntry*,
                             RlOpenDev*, RlOpenCtl*);
+std::atomic<uint64_t> g_variant_launches[16]; // rl_debug_variant_launches: launches per instantiation since the library was loaded
 TraceKernel trace_kernel_variant(bool stage, bool fused, bool open, bool cyl) {
+    g_variant_launches[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)].fetch_add(1, std::memory_order_relaxed);
     static const TraceKernel table[16] = {
         rl_trace_kernel<false, false, false, false>, rl_trace_kernel<false, false, false, true>,
         rl_trace_kernel<false, false, true, false>,  rl_trace_kernel<false, false, true, true>,
@@ -1636,6 +1638,14 @@ int rl_debug_batch_histogram(int device, uint64_t* out) {
                 device, (unsigned long long)d->calls, d->presync_us / d->calls, d->admit_us / d->calls, d->wait_us / d->calls);
     d->presync_us = d->admit_us = d->wait_us = 0.0;
     d->calls = 0;
+    return RL_OK;
+}
+
+// Diagnostics: launches of each instantiation of the trace kernel since the library was loaded; index = 8 * (primitives staged
+// in LDS) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound).
+int rl_debug_variant_launches(uint64_t* out) {
+    if (!out) return fail(RL_E_INVALID, "null argument");
+    for (int k = 0; k < 16; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
     return RL_OK;
 }
 

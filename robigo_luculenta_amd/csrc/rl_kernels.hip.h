@@ -310,6 +310,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     RlLdsU32* ring_s = (RlLdsU32*)ws->ring_s;
     uint32_t a_head = 0, a_tail = 0, b_head = 0, b_tail = 0, s_head = 0, s_tail = 0; // wave-uniform ring indices
     const RlF4* sph = sv.spheres;
+    // The scene's counts are launch constants.  Whatever is derived from them -- "is there any", "how many full groups of
+    // four", the member loop's choice -- is loop-invariant over the kernel's persistent loop too, and the optimiser keeps
+    // every such flag in a scalar register PAIR (a lane mask) across it: more than the register file holds, the rest is
+    // spilled to lanes of a vector register and read back with v_readlane (half-rate VALU).  Opaque copies: the flags are
+    // one s_cmp each where they are used.
+    uint32_t n_parabs = sv.n_parabs, n_planes = sv.n_planes, n_direct = sv.n_direct, cluster_k = sv.cluster_k;
+    asm volatile("" : "+s"(n_parabs), "+s"(n_planes), "+s"(n_direct), "+s"(cluster_k), "+s"(n_cluster_groups), "+s"(n_prism_groups), "+s"(group_gc));
 
     // Paraboloids, planes and circles: a handful of records, evaluated in registers.
     RlHit best;
@@ -317,7 +324,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     best.obj = RL_HIT_NONE;
     best.sub = 0;
     RL_T0(t_small);
-    for (uint32_t i = 0; i < sv.n_parabs; ++i) {
+    for (uint32_t i = 0; i < n_parabs; ++i) {
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
         const uint32_t obj = rl_f2u(r0.w);
@@ -326,7 +333,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             best.obj = obj;
         }
     }
-    for (uint32_t i = 0; i < sv.n_planes; ++i) {
+    for (uint32_t i = 0; i < n_planes; ++i) {
         const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];
         float dn;
         const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
@@ -399,8 +406,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // ---- direct spheres: every ray against every record; groups of 4 with one group of prefetch, then
     // the remainder one by one (the padding of rl_scene.h keeps every prefetch in bounds) ----
     RL_T0(t_direct);
-    if (sv.n_direct != 0) {
-        const uint32_t full = sv.n_direct & ~3u;
+    if (n_direct != 0) {
+        const uint32_t full = n_direct & ~3u;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
         for (uint32_t i = 0; i < full; i += 4) {
             const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
@@ -410,7 +417,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             RL_SPHERE_REJECT(c3, i + 3, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
-        for (uint32_t i = full; i < sv.n_direct; ++i) {
+        for (uint32_t i = full; i < n_direct; ++i) {
             const RlF4 next = sph[i + 1];
             uint32_t pos = i; // opaque: (full << 6) | lane is loop-invariant over the PERSISTENT loop too, gets hoisted out of
             asm volatile("" : "+s"(pos)); // it into a vector register that lives through the whole kernel -- and spills
@@ -437,13 +444,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // SPLIT (the plain launches; the open ones have no registers to spare for it): a round of at most 32 pairs -- 18 % of
         // them, the flush at the end of the sphere pass -- gives every pair two lanes, each with half of the members: half the
         // loop for the same round.
-        const uint32_t n_members = sv.cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
+        const uint32_t n_members = cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
         const bool split = SPLIT && count <= 32u && (n_members == 10u || n_members == 14u);
         const uint32_t slot = split ? (lane & 31u) : lane;
         const uint32_t e = ring_a[(a_head + slot) & 127u];
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
-        uint32_t first = sv.cluster_base + (sv.cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
+        uint32_t first = sv.cluster_base + (cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
         if (split) first += (lane >> 5) * (n_members >> 1);
         RlCullRay r;
         float r_far;
@@ -662,6 +669,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         base = smem;
         scratch = (RlWaveScratch*)(smem + lay.total_f4);
     }
+
     RlSceneView sv;
     sv.spheres = base;
     sv.planes = base + lay.off_planes;
@@ -681,7 +689,6 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     sv.n_prisms = lay.n_prisms;
     sv.n_objects = lay.n_objects;
     sv.camera_rec = base + lay.off_camera;
-
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
     typedef __attribute__((address_space(3))) float RlLdsF32;
@@ -800,7 +807,9 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
-                const RlSplat sp = rl_splat_weights(job.width, job.height, job.wm1, job.hm1, job.aspect_ratio, sx, sy);
+                uint32_t width = job.width, height = job.height; // opaque: `width - 1` etc. are re-derived here instead of living in
+                asm volatile("" : "+s"(width), "+s"(height));    // scalar registers across the persistent loop (and spilling)
+                const RlSplat sp = rl_splat_weights(width, height, job.wm1, job.hm1, job.aspect_ratio, sx, sy);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float* px = target + 3ull * sp.idx[k];
@@ -925,7 +934,9 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                             const unsigned long long now = wall_clock64(), since = finishing ? od->stuck_since : od->idle_since;
                             // (a call that never completes would be a bug in the counting above: after 5 s without one
                             // the launch ends regardless, and the host reports the call that is missing)
-                            const unsigned long long limit = finishing ? 500000000ull : (unsigned long long)job.grace_ticks;
+                            uint32_t grace = job.grace_ticks;
+                            asm volatile("" : "+s"(grace));
+                            const unsigned long long limit = finishing ? 500000000ull : (unsigned long long)grace;
                             if (since == 0) (finishing ? od->stuck_since : od->idle_since) = now, stay = 1;
                             else if (now - since < limit) stay = 1;
                             if (!finishing) od->stuck_since = 0;
@@ -1338,6 +1349,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __res
 // fn: 0 sin 1 cos 2 tan 3 exp 4 log 5 acos 6 sf10 ior 7 sqrt 8 a/b (y = x[i] / x[i+1 mod n]) 9 powf(x, 1/2.4)
 // 10: rl_roulette_ends(unit = x[i], continue_chance = x[m + i], intensity = x[2m + i]) for i < m = n / 3 (1 or 0)
 // 11: rl_normalise((x[i], x[m + i], x[2m + i])) -> (y[i], y[m + i], y[2m + i])
+// 12 sin 13 cos 14 exp 15 acos in their f64-evaluated forms (rl_*_d: scene construction, out-of-domain arguments)
 __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float* __restrict__ y, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (fn == 10) { // whole waves take part: the fast path is a wave-uniform decision
@@ -1366,6 +1378,10 @@ __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float*
     case 7: r = sqrtf(v); break;
     case 8: r = v / x[(i + 1) % n]; break;
     case 9: r = rl_powf(v, 1.0f / 2.4f); break;
+    case 12: r = rl_sinf_d(v); break;
+    case 13: r = rl_cosf_d(v); break;
+    case 14: r = rl_expf_d(v); break;
+    case 15: r = rl_acosf_d(v); break;
     }
     y[i] = r;
 }

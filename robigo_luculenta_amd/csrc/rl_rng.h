@@ -29,6 +29,13 @@ RL_HD uint32_t rl_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t
 
 RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The key (the launch's seed) is wave-uniform and loop-invariant over the trace kernel's persistent loop: left alone, the
+    // optimiser hoists the whole key schedule -- 18 sums key + round * W -- out of that loop into scalar registers that
+    // then do not fit (spilled to lanes of a vector register and read back with v_readlane).  Opaque here, the schedule
+    // is 18 s_add_i32 per block on the otherwise idle scalar unit.
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #if defined(__HIPCC__)
 #pragma unroll
 #endif

@@ -81,7 +81,7 @@ void push_prism_ring(std::vector<RlObjectDesc>& out, float sun_radius, int count
         for (int v = 0; v < 2; ++v) {
             const float ofs = variants[v][0], radius = variants[v][1], phi_ofs = variants[v][2], h = variants[v][3];
             const float phi = (float)i * prism_angle + ofs;
-            RlF3 position = rl_f3(rl_cosf(phi) * prism_radius * radius, rl_sinf(phi) * prism_radius * radius, 0.0f);
+            RlF3 position = rl_f3(rl_cosf_d(phi) * prism_radius * radius, rl_sinf_d(phi) * prism_radius * radius, 0.0f);
             RlF3 normal = rl_f3(0, 0, -1.0f);
             // Shoot straight down at the floor to find where the prism stands and how it leans.
             const float t = rl_paraboloid_t(floor.offset, floor.normal, floor.focal_point, position, normal);
@@ -123,7 +123,7 @@ void demo_scene(int seeds, std::vector<RlObjectDesc>& out) {
     for (int i = first_seed; i < first_seed + seeds; ++i) { // app.rs:239-253
         const float phi = (float)i * gamma;
         const float r = sqrtf((float)i) * seed_scale;
-        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.5f), rl_f3(0, 0, 0));
+        const RlF3 c = rl_add(rl_f3(rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * -0.5f), rl_f3(0, 0, 0));
         out.push_back(sphere(c, seed_size, RL_MATERIAL_DIFFUSE_COLOURED, 0.9f,
                              (float)(i - first_seed) / (float)seeds * 130.0f + 600.0f, 60.0f));
     }
@@ -131,14 +131,14 @@ void demo_scene(int seeds, std::vector<RlObjectDesc>& out) {
         const float fi = (float)i + 0.5f;
         const float phi = fi * gamma;
         const float r = sqrtf(fi) * seed_scale;
-        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * -0.25f), rl_f3(0, 0, 0));
+        const RlF3 c = rl_add(rl_f3(rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * -0.25f), rl_f3(0, 0, 0));
         out.push_back(sphere(c, seed_size * 0.5f, RL_MATERIAL_GLOSSY_MIRROR, 0.1f));
     }
     for (int i = first_seed / 2; i < first_seed + seeds; ++i) { // app.rs:271-284
         const float phi = (float)(-i) * gamma;
         const float root = sqrtf((float)i);
         const float r = root * seed_scale * 1.5f;
-        const RlF3 c = rl_add(rl_f3(rl_cosf(phi) * r, rl_sinf(phi) * r, (r - sun_radius) * 1.5f + sun_radius * 2.0f), rl_f3(0, 0, 0));
+        const RlF3 c = rl_add(rl_f3(rl_cosf_d(phi) * r, rl_sinf_d(phi) * r, (r - sun_radius) * 1.5f + sun_radius * 2.0f), rl_f3(0, 0, 0));
         out.push_back(sphere(c, seed_size * (0.5f + root * 0.2f), RL_MATERIAL_SOAP_BUBBLE));
     }
     push_prism_ring(out, sun_radius, 11, 17.0f);
@@ -159,7 +159,7 @@ void push_infinite_prism(std::vector<RlF4>& recs, RlF3 axis, RlF3 offset, float 
     const float radius = sqrtf(3.0f) / 6.0f * edge_length;
     const float a[3] = {angle, angle + PI * 2.0f / 3.0f, angle + PI * 4.0f / 3.0f};
     for (int k = 0; k < 3; ++k) {
-        const RlF3 p = rl_rotate_towards(rl_f3(rl_cosf(a[k]), rl_sinf(a[k]), 0.0f), axis);
+        const RlF3 p = rl_rotate_towards(rl_f3(rl_cosf_d(a[k]), rl_sinf_d(a[k]), 0.0f), axis);
         recs.push_back(F4(p, 0.0f));
         recs.push_back(F4(rl_add(rl_mul(p, radius), offset), objbits));
     }

@@ -30,7 +30,8 @@ def test_device_present():
 
 
 @pytest.mark.parametrize("fn,lo,hi", [("sin", -20, 20), ("cos", -20, 20), ("tan", 0.1, 1.4), ("exp", -100, 10),
-                                      ("log", 1e-6, 100), ("acos", -0.999, 0.999)])
+                                      ("log", 1e-6, 100), ("acos", -0.999, 0.999), ("sin", -300, 300), ("cos", 25, 40), ("exp", -120, 95),
+                                      ("acos", -1, 1), ("sin_d", -20, 20), ("cos_d", -300, 300), ("exp_d", -100, 10), ("acos_d", -1, 1)])
 def test_math_header_bit_exact_on_device(fn, lo, hi):
     rng = np.random.default_rng(7)
     x = rng.uniform(lo, hi, 1 << 16).astype(np.float32)
@@ -140,6 +141,56 @@ def test_trace_photons_bit_exact_glass_and_replicated():
             want, segs = oscene.render(W, H, 9, 1, 123, N, threads=8)
             assert t.mapped_photons.tobytes() == want.tobytes()
             assert t.stats()[1] == segs
+
+
+_MATRIX_SCENES = {}
+
+
+@pytest.mark.parametrize("scene_name", ["demo", "glass"])           # demo: prisms without a second bound; glass stress: with (CYL)
+@pytest.mark.parametrize("open_launch", [False, True], ids=["plain", "open"])
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+@pytest.mark.parametrize("fetch", [R.FETCH_LDS, R.FETCH_GLOBAL], ids=["lds", "global"])
+def test_parity_matrix_over_all_sixteen_instantiations(fetch, fused, open_launch, scene_name):
+    """every instantiation rl_trace_kernel<fetch, fused, open, cyl> against the oracle, and
+    rl_debug_variant_launches says that the instantiation meant is the one that ran.  Un-fused: MappedPhoton records byte
+    for byte.  Fused: the unit's (paths, segments) counters equal the oracle's and the splatted XYZ buffer equals
+    PlotUnit::plot of the oracle's photons up to the order of the float atomics (rtol 2e-5, as in
+    test_plot_fused_and_unfused_match_oracle)."""
+    if scene_name not in _MATRIX_SCENES:
+        objs, cam = R.builtin_scene_desc(R.SCENE_DEMO if scene_name == "demo" else R.SCENE_GLASS_STRESS)
+        _MATRIX_SCENES[scene_name] = (R.Scene(objs, cam), O.Scene(objs, _ocam(cam)), {})
+    scene, oscene, cache = _MATRIX_SCENES[scene_name]
+    W, H, N = 640, 360, 1 << 15                                   # a multiple of 64: blocking calls go through open launches
+    seed, stream, first = 5, 2, 777
+    if "want" not in cache:
+        cache["want"] = oscene.render(W, H, seed, stream, first, N, threads=8)
+    want, segs = cache["want"]
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    t.set_fetch(fetch)
+    before = R.variant_launches()
+    if not fused:
+        if open_launch:
+            t.render(scene, seed=seed, stream=stream, first_path_index=first)          # blocking: appended to an open launch
+        else:
+            t.render_async(scene, seed=seed, stream=stream, first_path_index=first)    # one plain launch
+            t.sync()
+        assert t.mapped_photons.tobytes() == want.tobytes()
+    else:
+        p = R.PlotUnit(0, W, H)
+        if open_launch:
+            t.render_fused_sync(scene, p, N, seed=seed, stream=stream, first_path_index=first)
+        else:
+            t.render_fused(scene, p, N, seed=seed, stream=stream, first_path_index=first)
+            t.sync()
+        got = p.tristimulus_buffer
+        ref = O.plot(W, H, want)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-6 * np.abs(ref).max())
+        assert got.any()
+    paths, segments, _ = t.stats()
+    assert (paths, segments) == (N, segs)
+    ran = [a - b for a, b in zip(R.variant_launches(), before)]
+    meant = (8 if fetch == R.FETCH_LDS else 0) | (4 if fused else 0) | (2 if open_launch else 0) | (1 if scene_name == "glass" else 0)
+    assert ran[meant] >= 1 and sum(ran) == ran[meant], (meant, ran)
 
 
 def test_ragged_batch_sizes(demo):

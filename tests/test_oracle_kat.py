@@ -12,6 +12,8 @@ import pytest
 
 import _oracle as O
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 f32 = np.float32
 PI = f32(math.pi)
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -75,20 +77,41 @@ def test_uniform_conversions_follow_rand_0_3():
 
 # ---- rl_math.h against numpy's libm ----------------------------------------------------------------
 
-@pytest.mark.parametrize("fn,ref,lo,hi", [
-    ("sin", np.sin, -25.0, 25.0), ("cos", np.cos, -25.0, 25.0), ("tan", np.tan, 0.05, 1.5),
-    ("exp", np.exp, -80.0, 20.0), ("log", np.log, 1e-30, 1e30), ("acos", np.arccos, -0.999, 0.999)])
-def test_math_header_within_one_ulp_of_libm(fn, ref, lo, hi):
+@pytest.mark.parametrize("fn,ref,lo,hi,correctly_rounded", [
+    # the per-bounce functions, f32 arithmetic (round 4): never farther than the neighbouring float of the correctly rounded
+    # value; of uniformly distributed arguments 97 % (sin, cos), 91 % (exp), 86 % (acos) ARE the correctly rounded value
+    ("sin", np.sin, -25.0, 25.0, 0.96), ("cos", np.cos, -25.0, 25.0, 0.96), ("exp", np.exp, -80.0, 20.0, 0.89), ("acos", np.arccos, -0.999, 0.999, 0.85),
+    ("sin", np.sin, -300.0, 300.0, 0.96), ("exp", np.exp, -110.0, 95.0, 0.89),   # (beyond |x| = 32 / below -86: the f64-evaluated forms)
+    # f64 evaluation, single rounding: almost always correctly rounded
+    ("sin_d", np.sin, -25.0, 25.0, 0.999), ("cos_d", np.cos, -25.0, 25.0, 0.999), ("exp_d", np.exp, -80.0, 20.0, 0.999),
+    ("acos_d", np.arccos, -0.999, 0.999, 0.999), ("tan", np.tan, 0.05, 1.5, 0.999), ("log", np.log, 1e-30, 1e30, 0.999)])
+def test_math_header_within_one_ulp_of_libm(fn, ref, lo, hi, correctly_rounded):
     rng = np.random.default_rng(1)
     if fn == "log":
         x = np.exp(rng.uniform(math.log(lo), math.log(hi), 200000)).astype(np.float32)
     else:
         x = rng.uniform(lo, hi, 200000).astype(np.float32)
     got = O.math_f32(fn, x)
-    want = ref(x.astype(np.float64)).astype(np.float32)
+    with np.errstate(over="ignore", under="ignore"):
+        want = ref(x.astype(np.float64)).astype(np.float32)
     d = ulp_diff(got, want)
     assert d.max() <= 1
-    assert (d == 0).mean() > 0.999  # f64 evaluation, single rounding: almost always correctly rounded
+    assert (d == 0).mean() > correctly_rounded
+
+
+def test_math_ulp_tool_sampled():
+    """tools/math_ulp_check.cpp over every 4096th f32 argument of each domain (the exhaustive run is profiles/r04_math_ulp.txt):
+    no result of either family is farther from the correctly rounded float than its neighbour."""
+    import subprocess, tempfile
+    exe = os.path.join(tempfile.mkdtemp(), "math_ulp_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-pthread", "-I", os.path.join(ROOT, "robigo_luculenta_amd", "csrc"),
+                    "-o", exe, os.path.join(ROOT, "tools", "math_ulp_check.cpp")], check=True)
+    out = subprocess.run([exe, "4096"], check=True, capture_output=True, text=True).stdout
+    rows = [l for l in out.splitlines() if "max error" in l]
+    assert len(rows) == 9
+    for l in rows:
+        assert "farther than the neighbour 0 " in l, l
+        assert float(l.split("max error")[1].split()[0]) < (1.1 if not "_d" in l.split()[0] else 0.5001), l
 
 
 def test_math_header_special_points():

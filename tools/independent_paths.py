@@ -13,15 +13,19 @@ share, by necessity, is the build's own definition of the two things the referen
   * the random numbers: Philox4x32-10 words addressed by (seed, stream, path, block, slot) with the slot
     assignment of csrc/rl_rng.h and rand 0.3.11's u32 -> f32 conversions.  Philox itself is
     re-implemented here in numpy (and checked against the Random123 known-answer vectors below);
-  * libm: sin, cos, tan, exp, acos (f32) and exp (f64) are evaluated by csrc/rl_math.h through the oracle
-    library, element-wise on arrays -- "the rl_math.h outputs fed in as arrays".  + - * / sqrt are numpy's
-    (IEEE-754, correctly rounded, never fused: every ufunc call is one rounding).
+  * libm: the per-path sin, cos, exp, acos (f32) and the f64 exp of Planck's law are evaluated by csrc/rl_math.h
+    through the oracle library, element-wise on arrays -- "the rl_math.h outputs fed in as arrays" -- when the
+    fixture is written (LIBM = "build").  The script also carries its OWN evaluation (LIBM = "platform": numpy's f64
+    functions rounded once to f32), used for everything computed once per scene and by `--libm-distance`, which counts
+    how many of the fixture's photons change when the build's libm is replaced by it.
+    + - * / sqrt are numpy's (IEEE-754, correctly rounded, never fused: every ufunc call is one rounding).
 
 This is still NOT a pin by the reference (the Rust crate cannot be built here and is unseedable); it
 removes the single-author risk on the glue of render_ray.
 
 Usage:  python tools/independent_paths.py            # writes tests/golden/independent_paths.npz
         python tools/independent_paths.py --check    # recomputes and compares with the committed fixture
+        python tools/independent_paths.py --libm-distance   # photons that differ under a platform libm
 """
 import os
 import sys
@@ -36,18 +40,37 @@ F = np.float32
 PI = F(np.pi)  # std::f32::consts::PI
 
 
-# ---- the shared libm, element-wise ---------------------------------------------------------------
+# ---- libm ------------------------------------------------------------------------------------------
+# LIBM = "build": the per-path transcendentals are the build's own definition (csrc/rl_math.h, evaluated element-wise
+# through the oracle's library) -- the fixture tests/golden/independent_paths.npz is computed this way and must be
+# reproduced bit for bit by the oracle and the GPU.
+# LIBM = "platform": this script's OWN evaluation -- numpy's f64 sin / cos / exp / arccos rounded once to f32, i.e. the
+# correctly rounded values that a good platform libm (what Rust's f32::sin etc. call) returns in all but rare cases.
+# `--libm-distance` counts the photons that differ between the two: the measured distance between "the build's libm"
+# and "a platform libm" (profiles/r04_libm_distance.txt).
+# Scene construction (set_up_scene, the prism constructors, the camera's tan) always uses the platform evaluation: the
+# build computes its scenes with the f64-evaluated forms (rl_sinf_d / rl_cosf_d / rl_tanf), which are the correctly
+# rounded values for every argument a scene uses.
+LIBM = "build"
+
 
 def _m(fn, x):
     x = np.asarray(x, dtype=F)
     return O.math_f32(fn, np.ascontiguousarray(x.reshape(-1))).reshape(x.shape)
 
 
-def sin(x): return _m("sin", x)
-def cos(x): return _m("cos", x)
-def tan(x): return _m("tan", x)
-def exp(x): return _m("exp", x)
-def acos(x): return _m("acos", x)
+def _own(fn, x):
+    with np.errstate(all="ignore"):
+        return fn(np.asarray(x, dtype=F).astype(np.float64)).astype(F)
+
+
+def sin(x): return _m("sin", x) if LIBM == "build" else _own(np.sin, x)
+def cos(x): return _m("cos", x) if LIBM == "build" else _own(np.cos, x)
+def exp(x): return _m("exp", x) if LIBM == "build" else _own(np.exp, x)
+def acos(x): return _m("acos", x) if LIBM == "build" else _own(np.arccos, x)
+def sin_scene(x): return _own(np.sin, x)
+def cos_scene(x): return _own(np.cos, x)
+def tan(x): return _own(np.tan, x)
 
 
 def exp64(x):
@@ -337,7 +360,7 @@ def new_infinite_prism(axis, offset, edge_length, angle):
     a1 = F(angle)
     a2 = F(angle) + PI * F(2.0) / F(3.0)
     a3 = F(angle) + PI * F(4.0) / F(3.0)
-    ps = [V(cos(a), sin(a), F(0.0)).rotate_towards(axis) for a in (a1, a2, a3)]
+    ps = [V(cos_scene(a), sin_scene(a), F(0.0)).rotate_towards(axis) for a in (a1, a2, a3)]
     sp1, sp2, sp3 = (SpacePartitioning(p, p * radius + offset) for p in ps)
     return Compound(Compound(sp1, sp2), sp3)
 
@@ -507,18 +530,18 @@ def set_up_scene(seeds=100, prism_rings=(17.0,), fixed_only=False):
     for i in range(first_seed, first_seed + seeds):
         phi = F(i) * gamma
         r = sqrt(F(i)) * seed_scale
-        position = V(cos(phi) * r, sin(phi) * r, (r - sun_radius) * F(-0.5)) + sun_position
+        position = V(cos_scene(phi) * r, sin_scene(phi) * r, (r - sun_radius) * F(-0.5)) + sun_position
         mat = DiffuseColoured(0.9, F(i - first_seed) / F(seeds) * F(130.0) + F(600.0), 60.0)
         objects.append((Sphere(position, seed_size), mat))
     for i in range(first_seed, first_seed + seeds):
         phi = (F(i) + F(0.5)) * gamma
         r = sqrt(F(i) + F(0.5)) * seed_scale
-        position = V(cos(phi) * r, sin(phi) * r, (r - sun_radius) * F(-0.25)) + sun_position
+        position = V(cos_scene(phi) * r, sin_scene(phi) * r, (r - sun_radius) * F(-0.25)) + sun_position
         objects.append((Sphere(position, seed_size * F(0.5)), GlossyMirror(0.1)))
     for i in (() if fixed_only else range(first_seed // 2, first_seed + seeds)):
         phi = F(-i) * gamma
         r = sqrt(F(i)) * seed_scale * F(1.5)
-        position = V(cos(phi) * r, sin(phi) * r, (r - sun_radius) * F(1.5) + sun_radius * F(2.0)) + sun_position
+        position = V(cos_scene(phi) * r, sin_scene(phi) * r, (r - sun_radius) * F(1.5) + sun_radius * F(2.0)) + sun_position
         objects.append((Sphere(position, seed_size * (F(0.5) + sqrt(F(i)) * F(0.2))), SoapBubble()))
 
     prisms = 11
@@ -527,7 +550,7 @@ def set_up_scene(seeds=100, prism_rings=(17.0,), fixed_only=False):
     for prism_radius, i in ((F(pr), i) for pr in prism_rings for i in range(prisms)):
         for ofs, radius, phi_ofs, h in ((F(0.0), F(1.0), F(0.0), F(1.0)), (F(0.5) * prism_angle, F(1.2), PI * F(0.5), F(1.5))):
             phi = F(i) * prism_angle + ofs
-            position = V(cos(phi) * prism_radius * radius, sin(phi) * prism_radius * radius, F(0.0))
+            position = V(cos_scene(phi) * prism_radius * radius, sin_scene(phi) * prism_radius * radius, F(0.0))
             normal = V(F(0.0), F(0.0), F(-1.0))
             hit = floor_paraboloid.intersect(position.broadcast(1), normal.broadcast(1))
             if bool(hit.some[0]):
@@ -655,8 +678,36 @@ def compute():
     return out
 
 
+def libm_distance():
+    """Photons of the fixture's cases that change when the per-path transcendentals are this script's own evaluation
+    (numpy f64, rounded once) instead of the build's rl_math.h."""
+    global LIBM
+    LIBM = "build"
+    a = compute()
+    LIBM = "platform"
+    b = compute()
+    LIBM = "build"
+    lines = []
+    total = changed = 0
+    for i in range(len(CASES)):
+        n = a["case%d_x" % i].size
+        diff = np.zeros(n, dtype=bool)
+        for f in ("x", "y", "probability", "wavelength"):
+            diff |= a["case%d_%s" % (i, f)].view(np.uint32) != b["case%d_%s" % (i, f)].view(np.uint32)
+        lines.append("case %d (scene %d, %d photons): %d photons differ, segments %d vs %d" % (
+            i, CASES[i][0], n, int(diff.sum()), int(a["case%d_segments" % i][0]), int(b["case%d_segments" % i][0])))
+        total += n
+        changed += int(diff.sum())
+    lines.append("total: %d of %d photons differ (%.3f %%) between the build's libm (csrc/rl_math.h) and numpy's f64 "
+                 "functions rounded once to f32" % (changed, total, 100.0 * changed / total))
+    return lines
+
+
 if __name__ == "__main__":
     target = os.path.join(ROOT, "tests", "golden", "independent_paths.npz")
+    if "--libm-distance" in sys.argv:
+        print("\n".join(libm_distance()))
+        sys.exit(0)
     got = compute()
     if "--check" in sys.argv:
         want = np.load(target)
