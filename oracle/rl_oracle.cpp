@@ -984,6 +984,13 @@ void oracle_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
     RlRngBlock b = rl_philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
     memcpy(out, b.w, 16);
 }
+// n blocks at once: out[4 i ..] = the words of (seed, stream, path[i], block[i])
+void oracle_rng_blocks(uint64_t seed, uint32_t stream, const uint64_t* path, const uint32_t* block, uint32_t* out, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i) {
+        RlRngBlock b = rl_rng_block(seed, stream, path[i], block[i]);
+        memcpy(out + 4 * i, b.w, 16);
+    }
+}
 void oracle_rng_block(uint64_t seed, uint32_t stream, uint64_t path, uint32_t block, uint32_t* out) {
     RlRngBlock b = rl_rng_block(seed, stream, path, block);
     memcpy(out, b.w, 16);

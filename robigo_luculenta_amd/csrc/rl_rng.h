@@ -2,8 +2,12 @@
 //
 // The reference draws from rand 0.3.11's OS-seeded thread-local generator (monte_carlo.rs:22-38),
 // which cannot be seeded, so "matched seed" has to be defined by the build: every draw is a pure
-// function of (seed, stream, path_index, block, slot).  Philox4x32-10 (Salmon et al., SC'11) is the
-// generator; one call yields the four 32-bit slots of one block.
+// function of (seed, stream, path_index, block, slot).  Philox4x32 (Salmon et al., SC'11) is the
+// generator; one call yields the four 32-bit slots of one block.  Rounds: RL_PHILOX_ROUNDS = 7, the fewest for which the
+// authors report the generator Crush-resistant (their Table 2; 10 is their default with a safety margin, and what rounds
+// 1-3 of this build used: the three rounds less are 1.2 % of the trace kernel's time).  The round function is pinned by
+// Random123's published 10-round vectors (rl_philox4x32_10, tests/test_oracle_kat.py), the 7-round words by an independent
+// numpy implementation over a million tuples (tests/test_independent.py).
 //
 //   block 0        : slot 0 wavelength, slot 1 screen x, slot 2 screen y, slot 3 camera time
 //                    (trace_unit.rs:154-158,138)
@@ -27,7 +31,9 @@ struct RlRngBlock {
 
 RL_HD uint32_t rl_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 
-RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#define RL_PHILOX_ROUNDS 7
+template <int ROUNDS>
+RL_HD RlRngBlock rl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #if defined(__HIP_DEVICE_COMPILE__)
     // The key (the launch's seed) is wave-uniform and loop-invariant over the trace kernel's persistent loop: left alone, the
@@ -39,7 +45,7 @@ RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < ROUNDS; ++round) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // One v_mad_u64_u32 (measured 5.0 cycles per wave) yields both halves of the 32x32 product; the
         // compiler otherwise emits v_mul_hi_u32 + v_mul_lo_u32 (4.4 + 4.7 cycles) for the constant multiplier.
@@ -69,10 +75,14 @@ RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     return r;
 }
 
+RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return rl_philox4x32<10>(c0, c1, c2, c3, k0, k1); // the published variant: known-answer tests
+}
+
 // One block of draws for (seed, stream, path, block).
 RL_HD RlRngBlock rl_rng_block(uint64_t seed, uint32_t stream, uint64_t path, uint32_t block) {
-    return rl_philox4x32_10((uint32_t)path, (uint32_t)(path >> 32), block, stream, (uint32_t)seed,
-                            (uint32_t)(seed >> 32));
+    return rl_philox4x32<RL_PHILOX_ROUNDS>((uint32_t)path, (uint32_t)(path >> 32), block, stream, (uint32_t)seed,
+                                           (uint32_t)(seed >> 32));
 }
 
 // rand 0.3.11 `random::<f32>()`: 24 random bits in [0, 1).

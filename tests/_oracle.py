@@ -70,6 +70,7 @@ def lib():
     L.oracle_material_bounce.restype = C.c_int
     L.oracle_material_bounce.argtypes = [u32, f32, f32, f32, vp, vp, u64, u32, u64, u32, vp]
     L.oracle_philox.argtypes = [vp, vp, vp]
+    L.oracle_rng_blocks.argtypes = [C.c_uint64, C.c_uint32, vp, vp, vp, C.c_uint64]
     L.oracle_rng_block.argtypes = [u64, u32, u64, u32, vp]
     L.oracle_math_f32.argtypes = [C.c_int, vp, vp, u64]
     L.oracle_powf.argtypes = [vp, f32, vp, u64]

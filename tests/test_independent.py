@@ -36,6 +36,33 @@ def scene_desc(R_or_mirror, which):
     return R_or_mirror.builtin_scene_desc(*((0, 0), (1, 0), (0, 158))[which])
 
 
+def test_the_builds_draws_against_an_rng_header_free_philox_over_a_million_tuples():
+    """csrc/rl_rng.h is shared by the product and the oracle, so Random123's four published vectors were the
+    only guard on it.  tools/independent_paths.py has its own numpy Philox (checked against the same published 10-round
+    vectors at import of this test); the oracle's words -- rl_rng_block through rl_rng.h, RL_PHILOX_ROUNDS rounds -- must
+    equal it for 2^20 random (seed, stream, path, block) tuples, path indices beyond 2^32 included."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import independent_paths as ip
+    ip._philox_kat()
+    rng = np.random.default_rng(2024)
+    n_tuples = 0
+    for _ in range(16):
+        seed = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+        stream = int(rng.integers(0, 1 << 32))
+        n = 1 << 16
+        path = rng.integers(0, 1 << 63, n, dtype=np.uint64) >> rng.integers(0, 40, n).astype(np.uint64)
+        block = rng.integers(0, 64, n).astype(np.uint32)
+        block[::97] = rng.integers(0, 1 << 32, len(block[::97])).astype(np.uint32)
+        got = np.zeros((n, 4), dtype=np.uint32)
+        O.lib().oracle_rng_blocks(seed, stream, O.ptr(path), O.ptr(block), O.ptr(got), n)
+        want = ip.philox4x32_10(path & np.uint64(0xffffffff), path >> np.uint64(32), block.astype(np.uint64),
+                                np.full(n, stream, dtype=np.uint64), seed & 0xffffffff, (seed >> 32) & 0xffffffff,
+                                rounds=ip.PHILOX_ROUNDS)
+        assert np.array_equal(got, np.stack(want, axis=1))
+        n_tuples += n
+    assert n_tuples == 1 << 20
+
+
 def test_oracle_matches_the_independent_restatement():
     import robigo_luculenta_amd as R   # host-only generators: no GPU needed
     total, scenes = 0, set()

@@ -29,10 +29,10 @@ def ulp_diff(a, b):
 
 # ---- random numbers ------------------------------------------------------------------------------
 
-def py_philox4x32_10(ctr, key):
+def py_philox4x32_10(ctr, key, rounds=10):
     M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
     c, k = list(ctr), list(key)
-    for r in range(10):
+    for r in range(rounds):
         if r:
             k = [(k[0] + W0) & 0xffffffff, (k[1] + W1) & 0xffffffff]
         p0, p1 = M0 * c[0], M1 * c[2]
@@ -59,8 +59,8 @@ def test_rng_block_keying():
     out = np.zeros(4, dtype=np.uint32)
     seed, stream, path, block = 0x1122334455667788, 7, 0x0000000512345678, 9
     O.lib().oracle_rng_block(seed, stream, path, block, O.ptr(out))
-    want = py_philox4x32_10([path & 0xffffffff, path >> 32, block, stream], [seed & 0xffffffff, seed >> 32])
-    assert list(out) == want
+    want = py_philox4x32_10([path & 0xffffffff, path >> 32, block, stream], [seed & 0xffffffff, seed >> 32], rounds=7)
+    assert list(out) == want                            # RL_PHILOX_ROUNDS = 7 (csrc/rl_rng.h)
 
 
 def test_uniform_conversions_follow_rand_0_3():

@@ -10,7 +10,7 @@ fixture this script writes (tests/golden/independent_paths.npz), bit for bit.  T
 the Rust sources only -- it shares no code with oracle/rl_oracle.cpp or csrc/rl_core.h.  What it does
 share, by necessity, is the build's own definition of the two things the reference leaves undefined:
 
-  * the random numbers: Philox4x32-10 words addressed by (seed, stream, path, block, slot) with the slot
+  * the random numbers: Philox4x32-7 words addressed by (seed, stream, path, block, slot) with the slot
     assignment of csrc/rl_rng.h and rand 0.3.11's u32 -> f32 conversions.  Philox itself is
     re-implemented here in numpy (and checked against the Random123 known-answer vectors below);
   * libm: the per-path sin, cos, exp, acos (f32) and the f64 exp of Planck's law are evaluated by csrc/rl_math.h
@@ -85,14 +85,17 @@ def sqrt(x):
         return np.sqrt(np.asarray(x, dtype=F))
 
 
-# ---- Philox4x32-10 (Salmon et al., SC'11), numpy ----------------------------------------------------
+# ---- Philox4x32 (Salmon et al., SC'11), numpy: 10 rounds for the published known answers, PHILOX_ROUNDS for the draws --
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
+PHILOX_ROUNDS = 7  # csrc/rl_rng.h: RL_PHILOX_ROUNDS
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1, rounds=10):
     M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
     c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & np.uint64(0xffffffff) for c in (c0, c1, c2, c3))
     mask = np.uint64(0xffffffff)
     sh = np.uint64(32)
-    for _ in range(10):
+    for _ in range(rounds):
         p0 = M0 * c0
         p1 = M1 * c2
         hi0, lo0 = p0 >> sh, p0 & mask
@@ -117,7 +120,8 @@ def rng_block(seed, stream, path, block):
     """The four 32-bit words of (seed, stream, path, block): csrc/rl_rng.h's addressing."""
     path = np.asarray(path, dtype=np.uint64)
     return philox4x32_10(path & np.uint64(0xffffffff), path >> np.uint64(32), np.full(path.shape, block, dtype=np.uint64),
-                         np.full(path.shape, stream, dtype=np.uint64), seed & 0xffffffff, (seed >> 32) & 0xffffffff)
+                         np.full(path.shape, stream, dtype=np.uint64), seed & 0xffffffff, (seed >> 32) & 0xffffffff,
+                         rounds=PHILOX_ROUNDS)
 
 
 def halfopen01(u):  # rand 0.3.11 random::<f32>(): top 24 bits * 2^-24
