@@ -222,18 +222,6 @@ __device__ __forceinline__ float rl_cull_margin(const RlCullRay& r, RlF4 b, floa
     const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
     return r.q - __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs);
 }
-// The same without the far bound (x = max(D.co, 0)): q - (cs - x^2), two operations less.
-__device__ __forceinline__ float rl_cull_margin_nofar(const RlCullRay& r, RlF4 b) {
-    const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
-    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
-    const float x = fmaxf(dd, 0.0f);
-    return __builtin_fmaf(x, x, r.q - cs);
-}
-#ifdef RL_AB_NOFAR_MEMBERS
-#define RL_MEMBER_MARGIN(R, B, FAR) rl_cull_margin_nofar(R, B)
-#else
-#define RL_MEMBER_MARGIN(R, B, FAR) rl_cull_margin(R, B, FAR)
-#endif
 __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b, float far) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
@@ -480,7 +468,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             uint32_t failed = 0; /* one bit per member: the sign of the test's margin, shifted in with one v_alignbit */  \
             for (uint32_t j = 0; j < (N); ++j) {                                                                         \
                 const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
-                failed = __builtin_amdgcn_alignbit(failed, rl_f2u(RL_MEMBER_MARGIN(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
+                failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
             }                                                                                                            \
             passed = slot < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
