@@ -208,7 +208,11 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
         "active_lanes": lanes,
         "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
         "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
-        "lds_bank_conflict_share_of_lds_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]) if c.get("SQ_ACTIVE_INST_LDS") else None,
+        # SQ_LDS_BANK_CONFLICT counts LDS-array cycles (one per extra address on a busy bank), summed over the CUs; GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs: conflict cycles per CU-cycle = the share of time a CU's LDS spends on conflicts (round 3 divided
+        # by SQ_ACTIVE_INST_LDS, a quad-cycle counter of something else -- VERDICT r03).  Attribution: profiles/r04_lds_conflicts.txt.
+        "lds_bank_conflict_cycles_per_cu_cycle": (c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)) if c.get("SQ_LDS_BANK_CONFLICT") else None,
+        "lds_bank_conflict_share_of_lds_array_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
         "wave_time": ({"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                        "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]} if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None),
         "profiled_launch_ms": d["kernel_ns"] / 1e6, "profiled_rays_per_launch": d["rays_per_launch"],
@@ -221,6 +225,89 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # MI355X_MICROARCH.md: FETCH_SIZE halves wide reads on gfx950
     return out, traffic
+
+
+LIVE_PASSES = (
+    "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE",
+    "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES GRBM_GUI_ACTIVE",
+)
+
+
+def executed_live(args, committed, timeout_s=100.0):
+    """the counter-derived figures measured in THIS run instead of quoted from a committed file.  After the
+    timed region, bench.py runs itself twice under `rocprofv3 --pmc` (the VALU pass and the wait pass of
+    tools/profile_round.sh) for one 256-batch launch of the same config and reads the trace kernel's last dispatch from the
+    counter CSVs.  Returns the same keys as `executed` plus `agrees` (with the committed profile, at 2 %); {"skipped": why}
+    when rocprofv3 is not on the box or a pass fails -- never an error: the bench line does not depend on it."""
+    import collections
+    import csv
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return {"skipped": "rocprofv3 is not on this box"}
+    t_begin = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="rl_live_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RL_BENCH_LIVE_CHILD="1")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--launches-per-step", "1", "--batches-per-launch", "256",
+             "--config", args.config, "--fetch", args.fetch, "--seed", str(args.seed), "--no-cpu-baseline", "--no-others", "--no-live-counters"]
+    c, line, kernel_ns = {}, None, []
+    try:
+        for i, counters in enumerate(LIVE_PASSES):
+            left = timeout_s - (time.perf_counter() - t_begin)
+            if left < 15.0:
+                return {"skipped": "no time left for counter pass %d" % i}
+            out_dir = os.path.join(tmp, "p%d" % i)
+            run = subprocess.run([prof, "--pmc"] + counters.split() + ["-f", "csv", "-d", out_dir, "-o", "p", "--"] + child, env=env, cwd="/tmp",
+                                 capture_output=True, timeout=left)
+            lines = [l for l in run.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            files = glob.glob(os.path.join(out_dir, "**", "p_counter_collection.csv"), recursive=True)
+            if run.returncode != 0 or not lines or not files:
+                return {"skipped": "counter pass %d failed (rc %d): %s" % (i, run.returncode, run.stderr.decode(errors="replace")[-300:])}
+            line = json.loads(lines[-1])
+            d = collections.defaultdict(lambda: collections.defaultdict(float))
+            ns = {}
+            for r in csv.DictReader(open(files[0])):
+                if "rl_trace" in r["Kernel_Name"]:
+                    d[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+                    ns[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if not d:
+                return {"skipped": "counter pass %d saw no trace kernel" % i}
+            k = sorted(d, key=int)[-1]
+            for name, v in d[k].items():
+                c.setdefault(name, v)     # (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE of the first pass that has them)
+            kernel_ns.append(ns[k])
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return {"skipped": "counter pass failed: %r" % (e,)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    segs64 = line["roofline"]["rays_per_launch"] / 64.0
+    cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / 1024.0)
+    lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    live = {
+        "how": "rocprofv3 --pmc around `bench.py --steps 1 --launches-per-step 1 --batches-per-launch 256` of this config, run by this "
+               "process after its timed region: two passes, last rl_trace_kernel dispatch of each",
+        "build_id": line["config"]["build_id"],
+        "valu_insts_per_64ray_segment": c["SQ_INSTS_VALU"] / segs64,
+        "cycles_per_valu_inst_per_simd": cyc,
+        "issue_frac_vs_2cyc": 2.0 / cyc,
+        "active_lanes": lanes,
+        "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
+        "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
+        "wave_time": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                      "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
+        "lds_bank_conflict_cycles_per_cu_cycle": c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0),
+        "lds_bank_conflict_share_of_lds_array_cycles": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
+        "profiled_launch_ms": sum(kernel_ns) / len(kernel_ns) / 1e6, "profiled_rays_per_launch": line["roofline"]["rays_per_launch"],
+        "seconds": time.perf_counter() - t_begin,
+    }
+    if committed and not committed.get("stale"):
+        keys = ("valu_insts_per_64ray_segment", "cycles_per_valu_inst_per_simd", "active_lanes", "useful_lane_slots_vs_2cyc")
+        live["vs_committed"] = {k: live[k] / committed[k] for k in keys}
+        live["agrees"] = all(abs(v - 1.0) <= 0.02 for v in live["vs_committed"].values())
+    else:
+        live["agrees"] = None
+    return live
 
 
 def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches, seed, device):
@@ -313,6 +400,18 @@ def rccl_report(world, rccl_used, info, sum_worlds, backend):
             "library": info.get("library"), "backend_used": "rccl" if rccl_used else backend}
 
 
+def scaling_detail(world, scaling, value, n1, other):
+    """`scaling_detail` of an N > 1 line: the one-GPU rate of the same run and both scaling modes against it.
+    efficiency = N-rank rays/s / (N x the one-GPU rays/s); SURVEY 8(e)'s target is >= 0.9 at N = 8."""
+    if n1 is None:
+        return None
+    out = {"n1_same_run": n1, scaling: {"value": value, "efficiency": value / (world * n1["value"]), "headline": True}}
+    if other is not None:
+        out[other["scaling"]] = dict(other, efficiency=other["value"] / (world * n1["value"]), headline=False)
+    out["efficiency_is"] = "whole-job Mrays/s / (n_gpus x n1_same_run.value); >= 0.9 is SURVEY 8(e)'s target"
+    return out
+
+
 def dry_run(args, D, R, rank, world, paths_per_launch, scaling):
     """The control plane and the line's N-rank fields without a GPU: every rank contributes made-up counters (rank r:
     1000 (r + 1) rays per path-thousand, 2 ms of exchange per step) through D.aggregate exactly like a real run."""
@@ -321,6 +420,11 @@ def dry_run(args, D, R, rank, world, paths_per_launch, scaling):
     rays = paths * (3.0 + rank)
     elapsed, (total_rays, total_paths) = D.aggregate(1.0 + 0.25 * rank, [rays, paths])
     exchange_ms, (sum_worlds, sum_exchanges, _) = D.aggregate(2.0 + rank, [world, args.steps, 0.0])
+    # the same-run one-GPU rate and the other scaling mode, made up the same way (rank 0 alone: 3 rays per path in 1 s per step)
+    n1 = {"value": paths / args.steps * 3.0 / 1.0 / 1e6, "unit": "Mrays/s", "steps": 1, "paths_per_step": paths / args.steps, "what": "dry run"}
+    o_dt, (o_rays, _) = D.aggregate((1.0 + 0.25 * rank) / world, [rays / world, paths / world])
+    other = {"scaling": "strong" if scaling == "weak" else "weak", "value": o_rays / o_dt / 1e6, "unit": "Mrays/s", "steps": args.steps,
+             "ms_per_step": o_dt / args.steps * 1e3, "paths_per_step_per_gpu": paths / args.steps / world, "what": "dry run"}
     if rank == 0:
         print(json.dumps({
             "metric": "Mrays/sec on built-in scene at 1920x1080", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
@@ -330,6 +434,7 @@ def dry_run(args, D, R, rank, world, paths_per_launch, scaling):
                        "dist_backend": "gloo (dry run)",
                        "rccl": rccl_report(world, False, {"rccl_version": 0, "library": None}, sum_worlds, "gloo (dry run)")},
             "mpaths_per_s": total_paths / elapsed / 1e6,
+            "scaling_detail": None if world == 1 else scaling_detail(world, scaling, total_rays / elapsed / 1e6, n1, other),
             "exchange": {"ms_per_step": exchange_ms, "per_step": sum_exchanges / world / args.steps, "share_of_step": exchange_ms / (elapsed / args.steps * 1e3)}}), flush=True)
     if world > 1:
         D.shutdown()
@@ -347,6 +452,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short runs of the other BASELINE configs (config.others)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="skip roofline.executed_live (bench.py re-running itself under rocprofv3 --pmc after the timed region, N = 1 only)")
     ap.add_argument("--total-paths", type=int, default=0,
                     help="strong scaling (SURVEY 8e): the paths of ONE STEP for the whole job, split evenly over the ranks "
                          "(rounded down to launches-per-step x 64 per rank); default 0 = weak scaling, the per-GPU work is fixed")
@@ -442,11 +549,28 @@ def main():
         else:
             gather.accumulate(plot)   # Kahan + clear (gather_unit.rs:49-64, app.rs:147)
 
-    def step():
+    def step(ppl=None, alone=False):
+        ppl = ppl or paths_per_launch
         for _ in range(args.launches_per_step):
-            trace.render_fused(scene, plot, paths_per_launch, seed=args.seed, stream=rank, first_path_index=next_path[0])
-            next_path[0] += paths_per_launch
-        gather_step()
+            trace.render_fused(scene, plot, ppl, seed=args.seed, stream=rank, first_path_index=next_path[0])
+            next_path[0] += ppl
+        if alone:
+            gather.accumulate(plot)   # rank 0 on its own: no exchange
+        else:
+            gather_step()
+
+    def timed(steps, ppl=None):
+        """`steps` steps between fences; returns (max-over-ranks seconds, total rays, total paths)."""
+        fence()
+        pa, sa, _ = trace.stats()
+        ta = time.perf_counter()
+        for _ in range(steps):
+            step(ppl)
+        fence()
+        tb = time.perf_counter()
+        pb, sb, _ = trace.stats()
+        dt, (r, q) = D.aggregate(tb - ta, [sb - sa, pb - pa])
+        return dt, r, q
 
     def fence():
         trace.sync()
@@ -462,6 +586,24 @@ def main():
     if args.warmup == 0 and world > 1:
         gather_step()  # build the communicator's rings outside the timed region (RCCL connects lazily)
     fence()
+    # an N-rank line that answers ">= 90 % of linear?" by itself.  Before the timed region rank 0 ALONE runs a
+    # few steps of the one-GPU workload (the others wait at the barrier): the N = 1 rate of this very run, on this very box.
+    n1 = None
+    if world > 1:
+        n1_steps = max(1, min(3, args.steps))
+        n1_ppl = args.batches_per_launch * BATCH if not args.total_paths else args.total_paths // args.launches_per_step // 64 * 64
+        if rank == 0:
+            trace.sync()
+            pa, sa, _ = trace.stats()
+            ta = time.perf_counter()
+            for _ in range(n1_steps):
+                step(n1_ppl, alone=True)
+            trace.sync(); plot.sync(); gather.sync()
+            tb = time.perf_counter()
+            pb, sb, _ = trace.stats()
+            n1 = {"value": (sb - sa) / (tb - ta) / 1e6, "unit": "Mrays/s", "steps": n1_steps, "paths_per_step": n1_ppl * args.launches_per_step,
+                  "what": "rank 0 alone (the other ranks idle at a barrier), same scene / resolution / launch structure, no exchange, before the timed region"}
+        fence()
     p0, s0, ms0 = trace.stats()
     ex_n0, ex_ms0 = plot.exchange_stats() if comm is not None else (0, 0.0)
     hx0 = list(host_exchange)
@@ -483,6 +625,21 @@ def main():
         my_exchange_ms, my_exchanges = (host_exchange[0] - hx0[0]) * 1e3 / args.steps, host_exchange[1] - hx0[1]
         info = {"world": world, "rccl_version": 0, "library": None}
     exchange_ms, (sum_worlds, sum_exchanges, sum_kernel_ms) = D.aggregate(my_exchange_ms, [info["world"], my_exchanges, kernel_ms])
+    # ... and the OTHER scaling mode in the same line: the headline is weak scaling (per-GPU work fixed: what the driver's --gpus N
+    # runs mean) unless --total-paths asks for strong; SURVEY 8(e) defines the metric on a fixed total, so the line carries both.
+    other = None
+    if world > 1:
+        if scaling == "weak":   # strong: ONE GPU's step split over the ranks
+            o_ppl = paths_per_launch // world // 64 * 64
+            o_name, o_what = "strong", "the paths of one GPU's step (%d) split evenly over the ranks" % (paths_per_launch * args.launches_per_step)
+        else:                   # weak: every rank renders the whole of --total-paths
+            o_ppl = args.total_paths // args.launches_per_step // 64 * 64
+            o_name, o_what = "weak", "every rank renders %d paths per step" % (o_ppl * args.launches_per_step)
+        if o_ppl >= 64:
+            o_steps = max(1, min(args.steps, 10))
+            o_dt, o_rays, o_paths = timed(o_steps, o_ppl)
+            other = {"scaling": o_name, "value": o_rays / o_dt / 1e6, "unit": "Mrays/s", "steps": o_steps, "ms_per_step": o_dt / o_steps * 1e3,
+                     "paths_per_step_per_gpu": o_ppl * args.launches_per_step, "what": o_what}
 
     if rank == 0:
         f_seg = flops_per_ray(objs)
@@ -522,6 +679,7 @@ def main():
                          "stream, max over ranks" % (3 * W * H)) if comm is not None else "host time of the gloo sum of the downloaded buffers, max over ranks",
                 "share_of_step": exchange_ms / (elapsed / args.steps * 1e3),
                 "kernel_share_of_step": (sum_kernel_ms / world) / (elapsed * 1e3)},
+            "scaling_detail": None if world == 1 else scaling_detail(world, scaling, total_rays / elapsed / 1e6, n1, other),
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                          # what the hardware did, first (profiles/*_pmc.json of this build; None when that profile is stale):
                          "frac_executed": executed.get("useful_lane_slots_vs_2cyc"),   # VALU lane-slots used / lane-slots at one wave64 instruction per 2 cycles per SIMD
@@ -534,6 +692,7 @@ def main():
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flops_per_ray": f_seg,
                          "executed": executed,
+                         "executed_live": None,   # filled in below (N = 1, rocprofv3 on the box): the same figures counted in this run
                          "traffic": traffic,
                          "hbm": ({"achieved": traffic / (launch_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": traffic / (launch_ms * 1e-3) / 8e12} if traffic else None),
@@ -546,6 +705,11 @@ def main():
             out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]
             workers = max(1, min(usable_cores(), 85))
             out["config"]["others"] += [measure_app(R, fused, workers, device) for fused in (False, True)]
+        if world == 1 and not args.no_live_counters and not os.environ.get("RL_BENCH_LIVE_CHILD"):
+            live = executed_live(args, executed)
+            out["roofline"]["executed_live"] = live
+            if not live.get("skipped") and executed.get("stale"):   # no committed profile of this build: the live counters lead
+                out["roofline"]["frac_executed"], out["roofline"]["valu_busy"] = live["useful_lane_slots_vs_2cyc"], live["issue_frac_vs_2cyc"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, objs, cam, W, H)
         print(json.dumps(out), flush=True)

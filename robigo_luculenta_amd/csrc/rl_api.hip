@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h> // fsync
 
 #include <chrono>
 #include <condition_variable>
@@ -124,7 +125,7 @@ struct RlTraceUnit {
     double kernel_ms;
     uint64_t launches;
     size_t tuned_dyn;  // launch configuration last set up for this unit: dynamic LDS bytes,
-    bool tuned_stage, tuned_fused; // kernel variant,
+    const void* tuned_kernel; // kernel instantiation,
     int tuned_per_cu;  // resident workgroups per CU (0 = not set up yet)
     std::shared_ptr<UnitCounters> counters = std::make_shared<UnitCounters>(); // of this unit's calls that open launches served
     Ticket ticket;                                                               // rl_trace_unit_render_begin
@@ -234,15 +235,14 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     const bool cyl = scene->lay.prism_cylinders != 0u;
     auto kernel = trace_kernel_variant(stage, fused, false, cyl);
     const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
-    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_stage != stage || u->tuned_fused != fused) { // once per (unit, scene size, variant)
+    if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_kernel != (const void*)kernel) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int per_cu = 1;
         RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
         u->tuned_per_cu = per_cu < 1 ? 1 : per_cu;
         u->tuned_dyn = dyn;
-        u->tuned_stage = stage;
-        u->tuned_fused = fused;
+        u->tuned_kernel = (const void*)kernel; // (the instantiation itself, not some of its template arguments -- `cyl` was not among them)
     }
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
     const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
@@ -492,8 +492,7 @@ int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t heigh
     u->kernel_ms = 0.0;
     u->launches = 0;
     u->tuned_dyn = 0;
-    u->tuned_stage = false;
-    u->tuned_fused = false;
+    u->tuned_kernel = nullptr;
     u->tuned_per_cu = 0;
     u->cu_count = 256;
     hipError_t e = hipMalloc((void**)&u->photons, (size_t)n_photons * sizeof(RlMappedPhoton));
@@ -1242,8 +1241,9 @@ int rl_gather_unit_save(RlGatherUnit* u, const char* path) {
     FILE* f = std::fopen(path, "wb");
     if (!f) return fail(RL_E_IO, std::string("failed to open file ") + path);
     const size_t written = std::fwrite(host.data(), sizeof(RlVector3), 2 * n, f);
+    const bool flushed = std::fflush(f) == 0 && fsync(fileno(f)) == 0; // on disk before a caller renames it into place (rl_app.cpp)
     const int closed = std::fclose(f);
-    if (written != 2 * n || closed != 0) return fail(RL_E_IO, std::string("failed to write raw buffer ") + path);
+    if (written != 2 * n || closed != 0 || !flushed) return fail(RL_E_IO, std::string("failed to write raw buffer ") + path);
     return RL_OK;
 }
 
@@ -1555,9 +1555,18 @@ int rl_plot_unit_reduce(RlPlotUnit* u, RlComm* comm, int root) {
         RL_HIP(hipEventCreate(&ep.start));
         RL_HIP(hipEventCreate(&ep.stop));
     }
-    RL_HIP(hipEventRecord(ep.start, u->stream));
-    RL_NCCL(api, api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream));
-    RL_HIP(hipEventRecord(ep.stop, u->stream));
+    // (Inside rl_comm_group_start / _end -- one thread driving several ranks -- RCCL enqueues the collective at GroupEnd, so both
+    // events land in front of it and the exchange reads as ~0 ms: rl_plot_unit_exchange_stats is meaningful for ungrouped
+    // reduces only, which is what bench.py's one-rank-per-process runs issue.)
+    hipError_t he = hipEventRecord(ep.start, u->stream);
+    ncclResult_t ne = ncclSuccess;
+    if (he == hipSuccess) ne = api->Reduce(u->xyz, u->xyz, count, ncclFloat32, ncclSum, root, (ncclComm_t)comm->nccl, u->stream);
+    if (he == hipSuccess && ne == ncclSuccess) he = hipEventRecord(ep.stop, u->stream);
+    if (he != hipSuccess || ne != ncclSuccess) {
+        u->exchange_pool.push_back(ep); // not leaked
+        if (ne != ncclSuccess) return fail(RL_E_HIP, std::string("ncclReduce: ") + api->GetErrorString(ne));
+        return fail(RL_E_HIP, std::string("hipEventRecord: ") + hipGetErrorString(he));
+    }
     u->exchanges.push_back(ep);
     return RL_OK;
 }

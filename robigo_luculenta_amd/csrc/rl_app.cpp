@@ -27,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h> // fsync
+
 #include "../../include/robigo_luculenta.h"
 
 void rl_internal_set_last_error(const std::string& msg); // rl_api.hip
@@ -42,6 +44,16 @@ struct Rank { // one GPU (or one RNG stream of a GPU that is listed twice)
     std::vector<RlPlotUnit*> plot_units;
 };
 
+// One line of the index: the buffer holds every path below next_batch * photons_per_batch of `ranks` RNG streams from `stream` on,
+// seed `seed`.  A buffer that was continued with another seed, or with streams it had not seen, holds several such sets;
+// the index keeps them ALL (rewriting it with only the current run's set forgot the older samples, and a later
+// resume with the original seed would have added them again).
+struct ResumeEntry {
+    unsigned long long next = 0, seed = 0;
+    unsigned ppb = 0, stream = 0;
+    size_t ranks = 0;
+};
+
 struct AppState {
     const RlAppConfig* cfg;
     RlScheduler* scheduler = nullptr;
@@ -51,6 +63,7 @@ struct AppState {
     RlGatherUnit* gather = nullptr;   // on rank 0's device
     RlTonemapUnit* tonemap = nullptr; // on rank 0's device
     uint64_t first_batch = 0;
+    std::vector<ResumeEntry> other_samples; // resume: what the loaded buffer holds of other seeds / RNG streams (kept in the index)
     std::mutex lock;                       // Arc<Mutex<TaskScheduler>>, app.rs:57
     std::mutex lock_counters;              // traces_issued, read by save_checkpoint outside `lock`
     std::chrono::steady_clock::time_point t0;
@@ -171,6 +184,25 @@ std::string sidecar_path(const char* checkpoint) { return std::string(checkpoint
 // order would add them twice on resume, which is bias.
 int replace_file(const std::string& tmp, const std::string& path) { return std::rename(tmp.c_str(), path.c_str()) == 0 ? RL_OK : RL_E_IO; }
 
+std::vector<ResumeEntry> read_sidecar(const char* checkpoint, uint32_t photons, const RlAppConfig* config, size_t ranks) {
+    std::vector<ResumeEntry> entries;
+    FILE* g = std::fopen(sidecar_path(checkpoint).c_str(), "r");
+    if (!g) return entries; // a buffer without an index (a reference run's buffer.raw): nothing to continue from
+    for (;;) {
+        ResumeEntry e;
+        const int got = std::fscanf(g, " next_batch %llu photons_per_batch %u seed %llu stream %u ranks %zu", &e.next, &e.ppb, &e.seed, &e.stream, &e.ranks);
+        if (got < 1) break;
+        if (got < 5) { // an index written by an older build: batches of the current size, the current streams
+            e.ppb = photons, e.seed = config->seed, e.stream = config->stream, e.ranks = ranks;
+            entries.push_back(e);
+            break;
+        }
+        entries.push_back(e);
+    }
+    std::fclose(g);
+    return entries;
+}
+
 int save_checkpoint(AppState& a) {
     uint64_t next;
     {
@@ -182,42 +214,39 @@ int save_checkpoint(AppState& a) {
     if (!f) return RL_E_IO;
     std::fprintf(f, "next_batch %llu\nphotons_per_batch %u\nseed %llu\nstream %u\nranks %zu\n", (unsigned long long)next, a.photons,
                  (unsigned long long)a.cfg->seed, a.cfg->stream, a.ranks.size());
-    if (std::fclose(f) != 0) return RL_E_IO;
+    for (const ResumeEntry& e : a.other_samples) // what the buffer already held of other seeds / streams when this run loaded it
+        std::fprintf(f, "next_batch %llu\nphotons_per_batch %u\nseed %llu\nstream %u\nranks %zu\n", e.next, e.ppb, e.seed, e.stream, e.ranks);
+    // on disk before the rename makes it the index: the index-before-buffer order must survive a power loss, not only a crash
+    const bool flushed = std::fflush(f) == 0 && fsync(fileno(f)) == 0;
+    if (std::fclose(f) != 0 || !flushed) return RL_E_IO;
     int rc = replace_file(side_tmp, side);
     if (rc != RL_OK) return rc;
     const std::string buf = a.cfg->checkpoint, buf_tmp = buf + ".tmp";
-    rc = rl_gather_unit_save(a.gather, buf_tmp.c_str());
+    rc = rl_gather_unit_save(a.gather, buf_tmp.c_str()); // (flushes and fsyncs before it closes the file)
     return rc != RL_OK ? rc : replace_file(buf_tmp, buf);
 }
 
-// Where a resumed run starts.  The sidecar records what the index counts (paths per batch) and which samples the buffer
-// holds (seed, first RNG stream, number of ranks = streams).  Same seed and the same streams: continue behind the recorded
-// path index, whatever the batch size is now.  Another seed, or streams the buffer has never seen: every sample is new,
-// the configured first_batch stands.  Same seed with streams that only partly overlap the recorded ones: some ranks
-// would repeat samples and others not -- refused.
-int resume_first_batch(const RlAppConfig* config, uint32_t photons, size_t ranks, uint64_t* first_batch, std::string* err) {
-    FILE* g = std::fopen(sidecar_path(config->checkpoint).c_str(), "r");
-    if (!g) return RL_OK; // a buffer without an index (a reference run's buffer.raw): nothing to continue from
-    unsigned long long next = 0, seed = 0;
-    unsigned ppb = 0, stream = 0;
-    size_t old_ranks = 0;
-    const int got = std::fscanf(g, "next_batch %llu photons_per_batch %u seed %llu stream %u ranks %zu", &next, &ppb, &seed, &stream, &old_ranks);
-    std::fclose(g);
-    if (got < 1) return RL_OK;
-    if (got < 5) { // an index written by an older build: batches of the current size, the current streams
-        ppb = photons, seed = config->seed, stream = config->stream, old_ranks = ranks;
+// Where a resumed run starts.  The index records what each of its sets counts (paths per batch) and which samples it stands for
+// (seed, first RNG stream, number of ranks = streams).  A set with this run's seed and streams: continue behind its path index,
+// whatever the batch size is now.  Sets of another seed, or of streams this run does not use: every sample of this run is new, the
+// configured first_batch stands -- and the sets are kept (`others`) so that the next index still lists them.  A set of this seed
+// whose streams only partly overlap this run's: some ranks would repeat samples and others not -- refused.
+int resume_first_batch(const RlAppConfig* config, uint32_t photons, size_t ranks, uint64_t* first_batch, std::vector<ResumeEntry>* others, std::string* err) {
+    for (const ResumeEntry& e : read_sidecar(config->checkpoint, photons, config, ranks)) {
+        const uint64_t lo = config->stream, hi = lo + ranks, olo = e.stream, ohi = olo + e.ranks;
+        if (e.seed != config->seed || hi <= olo || ohi <= lo) { // another seed, or disjoint streams
+            others->push_back(e);
+            continue;
+        }
+        if (lo != olo || hi != ohi) {
+            *err = "resume: the checkpoint holds RNG streams [" + std::to_string(olo) + ", " + std::to_string(ohi) + ") of this seed, the run asks for [" +
+                   std::to_string(lo) + ", " + std::to_string(hi) + "): some ranks would repeat samples";
+            return RL_E_STATE;
+        }
+        const unsigned __int128 paths = (unsigned __int128)e.next * e.ppb;
+        const uint64_t batch = (uint64_t)((paths + photons - 1) / photons); // the first batch of the current size that starts behind them
+        if (batch > *first_batch) *first_batch = batch;
     }
-    if (seed != config->seed) return RL_OK;
-    const uint64_t lo = config->stream, hi = lo + ranks, olo = stream, ohi = olo + old_ranks;
-    if (hi <= olo || ohi <= lo) return RL_OK; // disjoint streams
-    if (lo != olo || hi != ohi) {
-        *err = "resume: the checkpoint holds RNG streams [" + std::to_string(olo) + ", " + std::to_string(ohi) + ") of this seed, the run asks for [" +
-               std::to_string(lo) + ", " + std::to_string(hi) + "): some ranks would repeat samples";
-        return RL_E_STATE;
-    }
-    const unsigned __int128 paths = (unsigned __int128)next * ppb;
-    const uint64_t batch = (uint64_t)((paths + photons - 1) / photons); // the first batch of the current size that starts behind them
-    if (batch > *first_batch) *first_batch = batch;
     return RL_OK;
 }
 
@@ -468,7 +497,7 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
             rc = rl_gather_unit_load(a.gather, config->checkpoint);
             // Continue where the checkpointed run stopped handing out batches (see save_checkpoint).
             std::string why;
-            if (rc == RL_OK && (rc = resume_first_batch(config, a.photons, a.ranks.size(), &a.first_batch, &why)) != RL_OK) rl_internal_set_last_error(why);
+            if (rc == RL_OK && (rc = resume_first_batch(config, a.photons, a.ranks.size(), &a.first_batch, &a.other_samples, &why)) != RL_OK) rl_internal_set_last_error(why);
         }
     }
     a.fused_next_path = a.first_batch * (uint64_t)a.photons;

@@ -22,6 +22,10 @@
 #include "rl_rng.h"
 #include "rl_scene.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "rl_core.h's device fast paths (64-bit ballots, two scratch slots per lane, ds_bpermute batches) are written for wave64 gfx950"
+#endif
+
 struct RlF3 {
     float x, y, z;
 };
@@ -622,6 +626,10 @@ RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) 
 // first 2n lanes of the branch, evaluated in one pass and handed back.  More arguments than lanes: one pass each.
 RL_HD void rl_acos_pair(bool wanted, float a0, float a1, float* scratch, float* r0, float* r1) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // The device fast paths of this header (here, rl_normalise, rl_paraboloid_t, rl_roulette_ends) are written for a 64-wide
+    // wave: 64-bit ballots, 128 floats of scratch = two slots per lane.  `scratch` must be per-wave memory that nothing else
+    // uses while the caller's branch runs -- the trace kernel passes ring B, which is empty between two scans.
+    // (a build for another target stops at the #error at the head of this file)
     typedef __attribute__((address_space(3))) float LdsF32;
     LdsF32* slots = (LdsF32*)scratch;
     const uint64_t here = __builtin_amdgcn_ballot_w64(true), want = __builtin_amdgcn_ballot_w64(wanted);

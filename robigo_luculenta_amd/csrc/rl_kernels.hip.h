@@ -482,7 +482,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_MEMBERS
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
-            const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed);
+            const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed | 0x80000000u); // (a lane with nothing left does not push; ctz(0) is undefined)
             if (passed != 0u) ring_b[(b_tail + rl_mbcnt(any)) & 127u] = ((first + j) << 6) | owner;
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;

@@ -3,6 +3,7 @@
 #include "rl_scene.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -418,7 +419,10 @@ void improve_partition(const std::vector<Ball>& items, std::vector<std::vector<u
         v.erase(std::find(v.begin(), v.end(), i));
         return v;
     };
-    for (int pass = 0; pass < 8; ++pass) {
+    // (every candidate looks at all k bins for its neighbours: a pass is O(k^2 log k).  Scenes far beyond the ones this was
+    // tuned on get fewer passes -- planning time, never a result, depends on it)
+    const int passes = k <= 256 ? 8 : k <= 1024 ? 3 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
         bool improved = false;
         for (size_t a = 0; a < k; ++a) {
             if (bins[a].size() < 2) continue;

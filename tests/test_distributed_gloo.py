@@ -106,3 +106,12 @@ def test_the_n_rank_bench_line_says_what_the_exchange_ran_on_and_what_it_cost():
                           capture_output=True, timeout=300, env=dict(os.environ, MASTER_PORT=str(_free_port())))
     line = json.loads([l for l in weak.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert line["scaling"] == "weak" and line["config"]["paths_per_launch"] == 1024 * 524288
+    # the line answers ">= 90 % of linear?" by itself -- the one-GPU rate of the same run (rank 0 alone) and BOTH
+    # scaling modes against it, the headline's mode marked
+    sd = line["scaling_detail"]
+    assert sd["n1_same_run"]["value"] > 0 and sd["weak"]["headline"] is True and sd["strong"]["headline"] is False
+    assert sd["weak"]["value"] == pytest.approx(line["value"])
+    for mode in ("weak", "strong"):
+        assert sd[mode]["efficiency"] == pytest.approx(sd[mode]["value"] / (2 * sd["n1_same_run"]["value"]))
+    # the made-up ranks: (3 + r) rays per path in (1 + r / 4) s against rank 0 alone at 3 rays per path in 1 s per step
+    assert sd["weak"]["efficiency"] == pytest.approx((3.0 + 4.0) / 1.25 / (2 * 3.0))

@@ -227,6 +227,30 @@ def test_bench_runs_its_own_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["dist_backend"] == "gloo"
     assert line["mpaths_per_s"] > 0 and abs(line["segments_per_path"] - 3.54) < 0.1
     assert line["value"] > 0 and "cpu_baseline" not in line
+    # the line carries the one-GPU rate of the same run and both scaling modes (two ranks SHARING a GPU: efficiency ~ 0.5 or less)
+    sd = line["scaling_detail"]
+    assert sd["n1_same_run"]["value"] > 0 and sd["weak"]["headline"] and not sd["strong"]["headline"]
+    assert 0.05 < sd["weak"]["efficiency"] < 0.8 and 0.02 < sd["strong"]["efficiency"] < 0.8
+    assert sd["strong"]["paths_per_step_per_gpu"] == 2 * 524288
+
+
+def test_bench_line_counts_its_own_counters_when_rocprofv3_is_on_the_box():
+    """roofline.executed_live -- lane use and cycles per instruction counted in the bench's own run (bench.py
+    re-runs itself under rocprofv3 --pmc after the timed region), no committed file involved."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--launches-per-step", "1", "--batches-per-launch", "64",
+           "--no-cpu-baseline", "--no-others"]
+    out = subprocess.run(cmd, capture_output=True, timeout=600, check=True).stdout.decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    live = line["roofline"]["executed_live"]
+    assert live and not live.get("skipped"), live
+    assert live["build_id"] == line["config"]["build_id"]
+    assert 1500 < live["valu_insts_per_64ray_segment"] < 4000 and 2.0 < live["cycles_per_valu_inst_per_simd"] < 5.0
+    assert 0.6 < live["active_lanes"] < 1.0 and 0.3 < live["useful_lane_slots_vs_2cyc"] < 0.8
+    assert abs(sum(live["wave_time"].values()) - 1.0) < 0.15
+    assert live["seconds"] < 100
 
 
 def test_bench_with_more_ranks_than_gpus_falls_back_instead_of_hanging(R):
@@ -578,3 +602,12 @@ def test_resume_converts_the_index_when_the_batch_size_changed_and_refuses_overl
     assert "streams" in str(e.value)
     _, st4 = R.app_run(W, H, 2, checkpoint=raw, resume=True, photons_per_batch=n, concurrency=2, seed=10, fused=True)
     assert st4["next_batch"] == 2                                                          # a new seed: every sample is new
+    # ... and the index still lists seed 9's samples (the buffer still holds them), so a later resume with seed 9
+    # continues behind them instead of adding them a second time
+    words = open(raw + ".next").read().split()
+    assert words[:10] == ["next_batch", "2", "photons_per_batch", str(n), "seed", "10", "stream", "0", "ranks", "1"]
+    assert words[10:] == ["next_batch", str(4 * N), "photons_per_batch", str(n // 2), "seed", "9", "stream", "0", "ranks", "1"]
+    _, st5 = R.app_run(W, H, 1, checkpoint=raw, resume=True, photons_per_batch=n, concurrency=2, seed=9, fused=True)
+    assert st5["next_batch"] == 2 * N + 1                                                  # behind seed 9's 2N batches of n paths
+    words = open(raw + ".next").read().split()
+    assert words[:6] == ["next_batch", str(2 * N + 1), "photons_per_batch", str(n), "seed", "9"] and words[10:16] == ["next_batch", "2", "photons_per_batch", str(n), "seed", "10"]
