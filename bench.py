@@ -42,6 +42,7 @@ CONFIGS = {
     "demo-720p": ("demo", 0, 1280, 720),        # configs[1]
     "glass-720p": ("glass", 0, 1280, 720),      # configs[2]
     "replicated-1080p": ("demo", 158, 1920, 1080),  # configs[4]
+    "spill-1080p": ("demo", 1500, 1920, 1080),      # configs[4]'s "LDS-spill" half taken literally: 4,539 objects, does not fit LDS
     # ablation scenes (not BASELINE configs): prefixes of the demo scene's object list
     "ablate-noprisms": ("demo[:317]", 0, 1920, 1080),
     "ablate-fixed7": ("demo[:7]", 0, 1920, 1080),

@@ -2,7 +2,7 @@
 """Wave-level event counts of the trace kernel (diagnostic build `make -C robigo_luculenta_amd/csrc stats`,
 -DRL_STATS): how many compaction rounds of each kind an iteration runs and how full they are, which
 material branches a wave enters, how often the stash is refilled.  Sizes DESIGN.md's instruction budget.
-Usage (GPU box): python tools/kernel_stats.py [batches=16] [scene=demo|glass|replicated]"""
+Usage (GPU box): python tools/kernel_stats.py [batches=16] [scene=demo|glass|replicated|spill]"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,7 @@ NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 which = sys.argv[2] if len(sys.argv) > 2 else "demo"
 objs, cam = {"demo": lambda: R.builtin_scene_desc(R.SCENE_DEMO), "glass": lambda: R.builtin_scene_desc(R.SCENE_GLASS_STRESS),
-             "replicated": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 158)}[which]()
+             "replicated": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 158), "spill": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 1500)}[which]()
 scene = R.Scene(objs, cam)
 t, plot = R.TraceUnit(0, 1920, 1080, n_photons=64), R.PlotUnit(0, 1920, 1080)
 read = _lib.lib.rl_stats_read
