@@ -94,12 +94,8 @@ enum RlBuiltinScene {
 
 /* Where the trace kernel reads the primitive list from. */
 enum RlPrimitiveFetch {
-    RL_FETCH_LDS = 0,       /* the whole scene staged in LDS by each workgroup; a scene that does not fit is rendered as
-                             * RL_FETCH_GLOBAL (scene.rs:39-60 scans any object count) */
-    RL_FETCH_GLOBAL = 1,    /* the primitives' exact records from HBM/L2 (BASELINE config 5's forced run): LDS holds only the
-                             * tables every ray reads and 8-byte bounds of the clustered spheres; when even those do not fit,
-                             * as RL_FETCH_GLOBAL_ALL */
-    RL_FETCH_GLOBAL_ALL = 2 /* nothing staged: every record through wave-uniform loads from HBM/L2 (scalar cache) */
+    RL_FETCH_LDS = 0,   /* primitives + CIE tables staged in LDS by each workgroup */
+    RL_FETCH_GLOBAL = 1 /* wave-uniform loads from HBM/L2 through the scalar cache */
 };
 
 enum RlError {
@@ -155,7 +151,7 @@ int rl_scene_destroy(RlScene* scene);
 int rl_trace_unit_create(int device, uint32_t id, uint32_t width, uint32_t height, uint32_t n_photons,
                          RlTraceUnit** out);
 int rl_trace_unit_destroy(RlTraceUnit* unit);
-/* Selects RL_FETCH_LDS (default), RL_FETCH_GLOBAL or RL_FETCH_GLOBAL_ALL for subsequent renders. */
+/* Selects RL_FETCH_LDS (default) or RL_FETCH_GLOBAL for subsequent renders. */
 int rl_trace_unit_set_fetch(RlTraceUnit* unit, int primitive_fetch);
 /* TraceUnit::render(&mut self, &Scene) (trace_unit.rs:151-168): fills the unit's mapped_photons.
  * Photon i of this call is path (first_path_index + i) of RNG stream `stream` under `seed`.

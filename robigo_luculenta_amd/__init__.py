@@ -17,7 +17,7 @@ OBJECT_DTYPE = np.dtype([("surface_kind", "<u4"), ("material_kind", "<u4"), ("v0
 NUMBER_OF_PHOTONS = 1024 * 512  # trace_unit.rs:67
 
 SCENE_DEMO, SCENE_GLASS_STRESS = 0, 1
-FETCH_LDS, FETCH_GLOBAL, FETCH_GLOBAL_ALL = 0, 1, 2
+FETCH_LDS, FETCH_GLOBAL = 0, 1
 TASK_SLEEP, TASK_TRACE, TASK_PLOT, TASK_GATHER, TASK_TONEMAP = range(5)
 
 
@@ -400,8 +400,8 @@ def batch_histogram(device=0):
 
 def variant_launches():
     """rl_debug_variant_launches: launches per instantiation of the trace kernel since the library was loaded;
-    index = 8 * stage (0 nothing staged, 1 whole scene in LDS, 2 hybrid) + 4 * fused + 2 * open launch + 1 * prisms with a second bound."""
-    out = (C.c_uint64 * 24)()
+    index = 8 * staged in LDS + 4 * fused + 2 * open launch + 1 * prisms with a second bound."""
+    out = (C.c_uint64 * 16)()
     check(lib.rl_debug_variant_launches(out))
     return list(out)
 

@@ -84,8 +84,6 @@ struct RlScene {
     RlF4* blob;
     RlSceneLayout lay;
     size_t staged_bytes;
-    RlF4* hot_blob;   // what RL_STAGE_HYBRID stages (rl_kernels.hip.h); offsets in lay.hot_*
-    size_t hot_bytes;
 };
 
 namespace {
@@ -189,40 +187,22 @@ int drain_events(RlTraceUnit* u) {
 
 // The instantiation of rl_trace_kernel for a launch: primitives staged in LDS or fetched from global memory, fused with
 // the splat or not, an open launch or a plain one, prisms with a second bound or without.
-typedef void (*TraceKernel)(const RlF4*, const RlF4*, RlSceneLayout, RlTraceJob, RlMappedPhoton*, float*, unsigned long long*, const RlJobEntry*,
+typedef void (*TraceKernel)(const RlF4*, RlSceneLayout, RlTraceJob, RlMappedPhoton*, float*, unsigned long long*, const RlJobEntry*,
                             RlOpenDev*, RlOpenCtl*);
-std::atomic<uint64_t> g_variant_launches[24]; // rl_debug_variant_launches: launches per instantiation since the library was loaded
-TraceKernel trace_kernel_variant(int stage, bool fused, bool open, bool cyl) {
-    g_variant_launches[stage * 8 + (fused ? 4 : 0) + (open ? 2 : 0) + (cyl ? 1 : 0)].fetch_add(1, std::memory_order_relaxed);
-#define RL_VARIANTS_OF(STAGE)                                                                                              \
-    rl_trace_kernel<STAGE, false, false, false>, rl_trace_kernel<STAGE, false, false, true>, rl_trace_kernel<STAGE, false, true, false>, \
-        rl_trace_kernel<STAGE, false, true, true>, rl_trace_kernel<STAGE, true, false, false>, rl_trace_kernel<STAGE, true, false, true>, \
-        rl_trace_kernel<STAGE, true, true, false>, rl_trace_kernel<STAGE, true, true, true>
-    static const TraceKernel table[24] = {RL_VARIANTS_OF(RL_STAGE_GLOBAL), RL_VARIANTS_OF(RL_STAGE_LDS), RL_VARIANTS_OF(RL_STAGE_HYBRID)};
-#undef RL_VARIANTS_OF
-    return table[stage * 8 + (fused ? 4 : 0) + (open ? 2 : 0) + (cyl ? 1 : 0)];
-}
-
-// Where a launch reads the scene from, and with how many waves per workgroup (rl_kernels.hip.h: RL_STAGE_*).
-//   RL_FETCH_LDS         the whole blob in LDS if it fits beside the per-wave scratch, else as RL_FETCH_GLOBAL;
-//   RL_FETCH_GLOBAL      the primitives' exact records from global memory (BASELINE config 5's forced run): the hot part --
-//                        tables, direct spheres, 8-byte cluster members -- in LDS if THAT fits, with as many waves per workgroup
-//                        (16, 14 .. 8) as leave room for it; else as RL_FETCH_GLOBAL_ALL;
-//   RL_FETCH_GLOBAL_ALL  nothing staged.
-struct StageChoice {
-    int stage;
-    unsigned threads;
-    size_t dyn;
-};
-StageChoice choose_stage(const RlScene* scene, int fetch, bool open) {
-    const size_t lds = 160 * 1024, extra = open ? sizeof(RlOpenWg) : 0;
-    const size_t full = 16 * sizeof(RlWaveScratch) + extra;
-    if (fetch == RL_FETCH_LDS && scene->staged_bytes + full <= lds) return {RL_STAGE_LDS, 1024u, scene->staged_bytes + full};
-    if (fetch != RL_FETCH_GLOBAL_ALL && scene->hot_blob)
-        for (unsigned waves = 16; waves >= 8; waves -= 2)
-            if (scene->hot_bytes + waves * sizeof(RlWaveScratch) + extra <= lds)
-                return {RL_STAGE_HYBRID, waves * 64u, scene->hot_bytes + waves * sizeof(RlWaveScratch) + extra};
-    return {RL_STAGE_GLOBAL, 1024u, full};
+std::atomic<uint64_t> g_variant_launches[16]; // rl_debug_variant_launches: launches per instantiation since the library was loaded
+TraceKernel trace_kernel_variant(bool stage, bool fused, bool open, bool cyl) {
+    g_variant_launches[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)].fetch_add(1, std::memory_order_relaxed);
+    static const TraceKernel table[16] = {
+        rl_trace_kernel<false, false, false, false>, rl_trace_kernel<false, false, false, true>,
+        rl_trace_kernel<false, false, true, false>,  rl_trace_kernel<false, false, true, true>,
+        rl_trace_kernel<false, true, false, false>,  rl_trace_kernel<false, true, false, true>,
+        rl_trace_kernel<false, true, true, false>,   rl_trace_kernel<false, true, true, true>,
+        rl_trace_kernel<true, false, false, false>,  rl_trace_kernel<true, false, false, true>,
+        rl_trace_kernel<true, false, true, false>,   rl_trace_kernel<true, false, true, true>,
+        rl_trace_kernel<true, true, false, false>,   rl_trace_kernel<true, true, false, true>,
+        rl_trace_kernel<true, true, true, false>,    rl_trace_kernel<true, true, true, true>,
+    };
+    return table[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)];
 }
 
 // One launch of the trace kernel on u's stream: n_paths paths from first_path on, into `photons` (un-fused) or splatted
@@ -247,23 +227,25 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.wm1 = (float)(int)u->width - 1.0f;
     job.hm1 = (float)(int)u->height - 1.0f;
 
-    // One workgroup per CU: [staged part of the scene][per-wave scratch] in dynamic LDS.
-    const StageChoice sc = choose_stage(scene, u->fetch, false);
+    // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
+    const size_t blob_bytes = scene->staged_bytes;
+    const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
     const bool fused = plot != nullptr;
     const bool cyl = scene->lay.prism_cylinders != 0u;
-    auto kernel = trace_kernel_variant(sc.stage, fused, false, cyl);
-    const size_t dyn = sc.dyn;
+    auto kernel = trace_kernel_variant(stage, fused, false, cyl);
+    const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
     if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_kernel != (const void*)kernel) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int per_cu = 1;
-        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)sc.threads, dyn));
+        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
         u->tuned_per_cu = per_cu < 1 ? 1 : per_cu;
         u->tuned_dyn = dyn;
         u->tuned_kernel = (const void*)kernel; // (the instantiation itself, not some of its template arguments -- `cyl` was not among them)
     }
     uint64_t blocks = (uint64_t)u->cu_count * (uint64_t)u->tuned_per_cu;
-    const uint64_t needed = (n_paths + sc.threads - 1) / sc.threads;
+    const uint64_t needed = (n_paths + RL_TRACE_BLOCK - 1) / RL_TRACE_BLOCK;
     if (blocks > needed) blocks = needed;
 
     EventPair ep;
@@ -282,7 +264,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     }
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
     RL_HIP(hipEventRecord(ep.start, u->stream));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(sc.threads), dyn, u->stream, scene->blob, scene->hot_blob, scene->lay, job, photons,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
                        plot, u->queue, (const RlJobEntry*)nullptr, (RlOpenDev*)nullptr, (RlOpenCtl*)nullptr);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(ep.stop, u->stream));
@@ -454,42 +436,16 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
     lay.n_objects = (uint32_t)(fs.objects.size() / 2);
 
-    // The hot blob (RL_STAGE_HYBRID): direct spheres | planes | parabs | prisms | cull table | prism cylinders | camera | CIE | 8-byte members.
-    std::vector<RlF4> hot(fs.spheres.begin(), fs.spheres.begin() + std::min<size_t>(fs.spheres.size(), (size_t)fs.cluster_base + 4));
-    hot.resize((size_t)fs.cluster_base + 4, RlF4{0.0f, 0.0f, 0.0f, -std::numeric_limits<float>::infinity()}); // (the direct loop prefetches one group ahead)
-    auto append_hot = [&](const RlF4* first, size_t n) {
-        const uint32_t off = (uint32_t)hot.size();
-        hot.insert(hot.end(), first, first + n);
-        return off;
-    };
-    lay.hot_planes = append_hot(fs.planes.data(), fs.planes.size());
-    lay.hot_parabs = append_hot(fs.parabs.data(), fs.parabs.size());
-    lay.hot_prisms = append_hot(fs.prisms.data(), fs.prisms.size());
-    lay.hot_cull = append_hot(fs.cull_bounds.data(), fs.cull_bounds.size());
-    lay.hot_prism_cyl = append_hot(fs.prism_cyl.data(), fs.prism_cyl.size());
-    lay.hot_camera = append_hot(fs.camera_rec.data(), fs.camera_rec.size());
-    lay.hot_cie = append_hot(cie, RL_CIE_SAMPLES);
-    lay.hot_qmembers = (uint32_t)hot.size();
-    hot.resize(hot.size() + (fs.qmembers.size() + 1) / 2 + 1); // (+1: the member loop prefetches one entry ahead)
-    std::memcpy(hot.data() + lay.hot_qmembers, fs.qmembers.data(), fs.qmembers.size() * sizeof(uint64_t));
-    lay.hot_total_f4 = (uint32_t)hot.size();
-    lay.cluster_rmax2 = fs.cluster_rmax2;
-
     RlScene* s = new (std::nothrow) RlScene();
     if (!s) return fail(RL_E_INVALID, "out of host memory");
     s->device = device;
     s->lay = lay;
     s->staged_bytes = blob.size() * sizeof(RlF4);
     s->blob = nullptr;
-    s->hot_blob = nullptr;
-    s->hot_bytes = hot.size() * sizeof(RlF4);
     hipError_t e = hipMalloc((void**)&s->blob, s->staged_bytes);
     if (e == hipSuccess) e = hipMemcpy(s->blob, blob.data(), s->staged_bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->hot_blob, s->hot_bytes);
-    if (e == hipSuccess) e = hipMemcpy(s->hot_blob, hot.data(), s->hot_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         if (s->blob) (void)hipFree(s->blob);
-        if (s->hot_blob) (void)hipFree(s->hot_blob);
         delete s;
         return fail(RL_E_HIP, std::string("scene upload: ") + hipGetErrorString(e));
     }
@@ -508,7 +464,6 @@ int rl_scene_destroy(RlScene* scene) {
     (void)hipSetDevice(scene->device);
     (void)sessions_quiesce(scene->device); // an open launch may still be reading the blob
     (void)hipFree(scene->blob);
-    (void)hipFree(scene->hot_blob);
     delete scene;
     return RL_OK;
 }
@@ -582,7 +537,7 @@ int rl_trace_unit_destroy(RlTraceUnit* u) {
 
 int rl_trace_unit_set_fetch(RlTraceUnit* u, int primitive_fetch) {
     if (!u) return fail(RL_E_INVALID, "null trace unit");
-    if (primitive_fetch != RL_FETCH_LDS && primitive_fetch != RL_FETCH_GLOBAL && primitive_fetch != RL_FETCH_GLOBAL_ALL) return fail(RL_E_INVALID, "unknown fetch mode");
+    if (primitive_fetch != RL_FETCH_LDS && primitive_fetch != RL_FETCH_GLOBAL) return fail(RL_E_INVALID, "unknown fetch mode");
     u->fetch = primitive_fetch;
     return RL_OK;
 }
@@ -736,13 +691,14 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     job.reserved = 0;
     job.wm1 = (float)(int)u->width - 1.0f;
     job.hm1 = (float)(int)u->height - 1.0f;
-    const StageChoice sc = choose_stage(scene, u->fetch, true);
-    auto kernel = trace_kernel_variant(sc.stage, fused, true, scene->lay.prism_cylinders != 0u);
-    const size_t dyn = sc.dyn;
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
+    const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
+    auto kernel = trace_kernel_variant(stage, fused, true, scene->lay.prism_cylinders != 0u);
+    const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
     if (x.tuned_kernel != (const void*)kernel || x.tuned_dyn != dyn) { // once per (slot, variant, scene size)
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int n = 1;
-        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, (int)sc.threads, dyn));
+        RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, RL_TRACE_BLOCK, dyn));
         x.tuned_per_cu = n < 1 ? 1 : n;
         x.tuned_kernel = (const void*)kernel;
         x.tuned_dyn = dyn;
@@ -757,7 +713,7 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     RL_HIP(hipMemsetAsync(x.od, 0, sizeof(RlOpenDev), x.stream));
     RL_HIP(hipMemsetAsync(x.counters, 0, 3 * sizeof(unsigned long long), x.stream));
     RL_HIP(hipEventRecord(x.start, x.stream));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(u->cu_count * per_cu)), dim3(sc.threads), dyn, x.stream, scene->blob, scene->hot_blob, scene->lay, job,
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(u->cu_count * per_cu)), dim3(RL_TRACE_BLOCK), dyn, x.stream, scene->blob, scene->lay, job,
                        (RlMappedPhoton*)nullptr, (float*)nullptr, x.counters, (const RlJobEntry*)x.od->jobs, x.od, x.ctl_dev);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(x.stop, x.stream));
@@ -1694,11 +1650,11 @@ int rl_debug_batch_histogram(int device, uint64_t* out) {
     return RL_OK;
 }
 
-// Diagnostics: launches of each instantiation of the trace kernel since the library was loaded; index = 8 * stage (0 nothing staged,
-// 1 whole scene in LDS, 2 hybrid) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound).
+// Diagnostics: launches of each instantiation of the trace kernel since the library was loaded; index = 8 * (primitives staged
+// in LDS) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound).
 int rl_debug_variant_launches(uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
-    for (int k = 0; k < 24; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
+    for (int k = 0; k < 16; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
     return RL_OK;
 }
 

@@ -41,25 +41,7 @@ struct RlSceneLayout {
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
     uint32_t group_gc;                         // RlFlatScene::group_gc: clusters per group of the cull table
-    // RL_STAGE_HYBRID: offsets into the HOT blob (what a scene too large for LDS still stages there), in RlF4 units.  The direct
-    // spheres start at 0; qmembers are RlFlatScene::qmembers (8 bytes per cluster member, two per RlF4).
-    uint32_t hot_planes, hot_parabs, hot_prisms, hot_cull, hot_prism_cyl, hot_camera, hot_cie, hot_qmembers, hot_total_f4;
-    float cluster_rmax2;                       // RlFlatScene::cluster_rmax2
 };
-
-// Where the trace kernel reads the scene from (its first template argument).
-//   RL_STAGE_LDS     the whole blob is staged in LDS per workgroup (scenes up to ~600 objects).
-//   RL_STAGE_HYBRID  a scene whose blob does not fit: everything a ray reads wave-uniformly or tests conservatively is staged
-//                    -- planes, paraboloids, prisms, the direct spheres, the cull table, camera, CIE table, and the cluster
-//                    members as 8-byte balls relative to their cluster's centre (RlFlatScene::qmembers) -- while the exact
-//                    16-byte sphere records, the per-sphere arrays and the object table stay in global memory and are read
-//                    per lane only for the pairs that reach the exact test (ring B) and once per bounce.  The workgroup
-//                    shrinks (16 -> 14 .. 8 waves) to make room.  BASELINE config 5's "LDS-spill / global-HBM primitive path".
-//   RL_STAGE_GLOBAL  nothing staged: every record from global memory with wave-uniform (scalar) loads.  The last resort for a
-//                    scene whose hot part does not fit either (hundreds of prisms, tens of thousands of spheres).
-#define RL_STAGE_GLOBAL 0
-#define RL_STAGE_LDS 1
-#define RL_STAGE_HYBRID 2
 
 struct RlTraceJob {
     uint32_t width, height;
@@ -317,11 +299,8 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-// sph_uniform: the direct spheres as every ray reads them (the hot blob's copy when HYBRID, else sv.spheres); qmembers /
-// cluster_rmax2: RlFlatScene's, HYBRID only.
-template <bool HYBRID, bool CYL, bool SPLIT>
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* sph_uniform, const RlF4* cull, const RlF4* prism_cyl,
-                                              const unsigned long long* qmembers, float cluster_rmax2, uint32_t group_gc, float sv_cull_cmax2,
+template <bool CYL, bool SPLIT>
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
@@ -429,10 +408,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     RL_T0(t_direct);
     if (n_direct != 0) {
         const uint32_t full = n_direct & ~3u;
-        const RlF4* su = sph_uniform;
-        RlF4 c0 = su[0], c1 = su[1], c2 = su[2], c3 = su[3];
+        RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
         for (uint32_t i = 0; i < full; i += 4) {
-            const RlF4 n0 = su[i + 4], n1 = su[i + 5], n2 = su[i + 6], n3 = su[i + 7];
+            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
             RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             RL_SPHERE_REJECT(c1, i + 1, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
             RL_SPHERE_REJECT(c2, i + 2, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
@@ -440,7 +418,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
         for (uint32_t i = full; i < n_direct; ++i) {
-            const RlF4 next = su[i + 1];
+            const RlF4 next = sph[i + 1];
             uint32_t pos = i; // opaque: (full << 6) | lane is loop-invariant over the PERSISTENT loop too, gets hoisted out of
             asm volatile("" : "+s"(pos)); // it into a vector register that lives through the whole kernel -- and spills
             RL_SPHERE_REJECT(c0, pos, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
@@ -467,7 +445,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // them, the flush at the end of the sphere pass -- gives every pair two lanes, each with half of the members: half the
         // loop for the same round.
         const uint32_t n_members = cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
-        const bool split = SPLIT && !HYBRID && count <= 32u && (n_members == 10u || n_members == 14u);
+        const bool split = SPLIT && count <= 32u && (n_members == 10u || n_members == 14u);
         const uint32_t slot = split ? (lane & 31u) : lane;
         const uint32_t e = ring_a[(a_head + slot) & 127u];
         const uint32_t owner = e & 63u;
@@ -496,36 +474,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             passed = slot < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
             n_mine = (N);                                                                                                \
         }
-        if (HYBRID) {
-            // The members as 8-byte balls {x, y, z, R} (half floats) relative to the centre of the cluster's bound, from LDS: the ray's
-            // cull terms move into that frame once per pair (o' = o - centre: M' = M + 2 centre = -2 o', P' = -D.o' = D.M' / 2,
-            // the slack scaled by the clusters' extent instead of the scene's), each member costs four conversions and
-            // w' = |c'|^2 - R^2 on top of the test.  Conservative like the 16-byte form: the ball contains the sphere's cull
-            // ball (rl_scene.cpp rounds R up by the distance the rounded centre moved), the exact test follows in ring B.
-            const uint32_t ci = slot < count ? (e >> 6) : 0u;
-            const RlF4 bc = cull[ci];
-            RlCullRay rl = r;
-            rl.m = rl_f3(__builtin_fmaf(2.0f, bc.x, r.m.x), __builtin_fmaf(2.0f, bc.y, r.m.y), __builtin_fmaf(2.0f, bc.z, r.m.z));
-            const float o2 = 0.25f * __builtin_fmaf(rl.m.z, rl.m.z, __builtin_fmaf(rl.m.y, rl.m.y, rl.m.x * rl.m.x));
-            rl.p = 0.5f * __builtin_fmaf(r.d.z, rl.m.z, __builtin_fmaf(r.d.y, rl.m.y, r.d.x * rl.m.x));
-            rl.q = __builtin_fmaf(2.0e-5f, o2 + cluster_rmax2, -o2);
-            const unsigned long long* qm = qmembers + (size_t)n_members * ci;
-            uint32_t failed = 0;
-            unsigned long long rec = qm[0];
-            for (uint32_t j = 0; j < n_members; ++j) {
-                const unsigned long long rec_next = qm[j + 1]; // (behind the last member: the next cluster's first, or the blob's slack)
-                RlF4 mb;
-                mb.x = (float)__builtin_bit_cast(_Float16, (uint16_t)rec);
-                mb.y = (float)__builtin_bit_cast(_Float16, (uint16_t)(rec >> 16));
-                mb.z = (float)__builtin_bit_cast(_Float16, (uint16_t)(rec >> 32));
-                const float radius = (float)__builtin_bit_cast(_Float16, (uint16_t)(rec >> 48));
-                mb.w = __builtin_fmaf(mb.z, mb.z, __builtin_fmaf(mb.y, mb.y, __builtin_fmaf(mb.x, mb.x, -(radius * radius))));
-                failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(rl, mb, r_far)), 31u);
-                rec = rec_next;
-            }
-            passed = slot < count ? ~failed & ((1u << n_members) - 1u) : 0u;
-            n_mine = n_members;
-        } else if (n_members == 10u) {
+        if (n_members == 10u) {
             if (split) RL_MEMBERS(5u) else RL_MEMBERS(10u)
         } else if (n_members == 14u) {
             if (split) RL_MEMBERS(7u) else RL_MEMBERS(14u)
@@ -703,38 +652,31 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // plain launch -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
 // CYL: the scene's prisms carry a second bound (RlFlatScene::prism_cylinders) -- a compile-time switch so that scenes
 // without it run exactly the code they ran before it existed.
-template <int STAGE, bool FUSED, bool OPEN, bool CYL>
+template <bool STAGE_LDS, bool FUSED, bool OPEN, bool CYL>
 // At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
 // the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
-__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, const RlF4* __restrict__ hot, RlSceneLayout lay,
+__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
                                                                   RlTraceJob job, RlMappedPhoton* __restrict__ photons,
                                                                   float* __restrict__ plot,
                                                                   unsigned long long* __restrict__ queue,
                                                                   const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
-    constexpr bool STAGE_LDS = STAGE == RL_STAGE_LDS, HYBRID = STAGE == RL_STAGE_HYBRID;
     const RlF4* base = scene;
     RlWaveScratch* scratch = (RlWaveScratch*)smem;
-    const uint32_t n_waves = blockDim.x >> 6; // 16; a HYBRID launch may run fewer to make room for its tables
     if (STAGE_LDS) {
-        for (uint32_t i = threadIdx.x; i < lay.total_f4; i += blockDim.x) smem[i] = scene[i];
+        for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_TRACE_BLOCK) smem[i] = scene[i];
         __syncthreads();
         base = smem;
         scratch = (RlWaveScratch*)(smem + lay.total_f4);
     }
-    if (HYBRID) {
-        for (uint32_t i = threadIdx.x; i < lay.hot_total_f4; i += blockDim.x) smem[i] = hot[i];
-        __syncthreads();
-        scratch = (RlWaveScratch*)(smem + lay.hot_total_f4);
-    }
 
     RlSceneView sv;
-    sv.spheres = base; // (HYBRID: the exact records, in global memory)
-    sv.planes = HYBRID ? smem + lay.hot_planes : base + lay.off_planes;
-    sv.parabs = HYBRID ? smem + lay.hot_parabs : base + lay.off_parabs;
-    sv.prisms = HYBRID ? smem + lay.hot_prisms : base + lay.off_prisms;
+    sv.spheres = base;
+    sv.planes = base + lay.off_planes;
+    sv.parabs = base + lay.off_parabs;
+    sv.prisms = base + lay.off_prisms;
     sv.objects = base + lay.off_objects;
-    sv.cie = HYBRID ? smem + lay.hot_cie : base + lay.off_cie;
+    sv.cie = base + lay.off_cie;
     sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
     sv.sphere_r2 = (const float*)(base + lay.off_sphere_r2);
     sv.n_direct = lay.n_direct;
@@ -746,7 +688,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;
     sv.n_objects = lay.n_objects;
-    sv.camera_rec = HYBRID ? smem + lay.hot_camera : base + lay.off_camera;
+    sv.camera_rec = base + lay.off_camera;
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
     typedef __attribute__((address_space(3))) float RlLdsF32;
@@ -782,14 +724,14 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     bool pend_me = false;              // this lane's path finished in the last iteration (my_job is still its job)
     bool pend_any = false;             // wave-uniform: some lane's did
     uint32_t emit_pend = 0, emit_pend_base = 0; // wave-uniform: the emitter batch splatted in the last iteration
-    RlOpenWg* wgp = (RlOpenWg*)(scratch + n_waves);
+    RlOpenWg* wgp = (RlOpenWg*)(scratch + RL_TRACE_BLOCK / 64);
     RlLdsU32* wg_fin = (RlLdsU32*)&wgp->fin[0];
     RlLdsU32* wg_seg = (RlLdsU32*)&wgp->seg[0];
     RlLdsU32* wg_flushed_at = (RlLdsU32*)&wgp->flushed_at;
     RlLdsU32* wg_poll = (RlLdsU32*)&wgp->poll[0];
     RlLdsF32* emit = (RlLdsF32*)&ws->emit[0][0];
     if (OPEN) {
-        for (uint32_t i = threadIdx.x; i < sizeof(RlOpenWg) / 4; i += blockDim.x) ((RlLdsU32*)wgp)[i] = 0;
+        for (uint32_t i = threadIdx.x; i < sizeof(RlOpenWg) / 4; i += RL_TRACE_BLOCK) ((RlLdsU32*)wgp)[i] = 0;
         __syncthreads();
     }
     // counts the paths whose results were issued an iteration ago
@@ -1028,7 +970,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                     // batch is 2 per lane) take one stash refill at a time, so that every wave gets work;
                     // with RL_CHUNK the first half of the waves would take everything.
                     const unsigned long long chunk =
-                        job.n_paths >= (unsigned long long)gridDim.x * (blockDim.x * 16ull) ? RL_CHUNK : 64ull;
+                        job.n_paths >= (unsigned long long)gridDim.x * (RL_TRACE_BLOCK * 16ull) ? RL_CHUNK : 64ull;
                     unsigned long long b = 0;
                     if (lane == 0) b = atomicAdd(&queue[0], chunk);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
@@ -1102,11 +1044,8 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
             continue;
         }
-        const RlHit hit = rl_scan_wave<HYBRID, CYL, !OPEN>(sv, HYBRID ? (const RlF4*)smem : sv.spheres, HYBRID ? smem + lay.hot_cull : base + lay.off_cull,
-                                                            CYL ? (HYBRID ? smem + lay.hot_prism_cyl : base + lay.off_prism_cyl) : nullptr,
-                                                            HYBRID ? (const unsigned long long*)(smem + lay.hot_qmembers) : nullptr, lay.cluster_rmax2, lay.group_gc,
-                                                            lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin, p.direction,
-                                                            active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
+        const RlHit hit = rl_scan_wave<CYL, !OPEN>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+                                       p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
             const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? (rl_f2u(sv.objects[2 * hit.obj].x) >> 8) : 99u;

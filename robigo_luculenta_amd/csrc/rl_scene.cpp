@@ -12,46 +12,6 @@
 
 #include "rl_core.h"
 
-// IEEE half floats for RlFlatScene::qmembers (g++ 11 has no _Float16 on x86): the bits of x rounded to nearest-even, or up
-// (towards +infinity) -- finite |x| <= 65504 only, which is all the callers produce.
-uint16_t rl_f16_bits(float x, bool round_up);
-float rl_f16_value(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
-    float v;
-    if (e == 0) v = std::ldexp((float)m, -24);
-    else if (e == 31) v = m ? std::numeric_limits<float>::quiet_NaN() : std::numeric_limits<float>::infinity();
-    else v = std::ldexp((float)(m | 0x400u), (int)e - 25);
-    return sign ? -v : v;
-}
-uint16_t rl_f16_bits(float x, bool round_up) {
-    const bool neg = std::signbit(x);
-    const float a = std::fabs(x);
-    if (!(a <= 65504.0f)) return (uint16_t)((neg ? 0x8000u : 0u) | 0x7bffu); // clamp (callers check)
-    // the largest half not above a: by exponent, exactly
-    int e;
-    uint32_t bits;
-    if (a < 6.103515625e-05f) { // subnormal halves: multiples of 2^-24
-        bits = (uint32_t)std::floor(std::ldexp(a, 24));
-    } else {
-        std::frexp(a, &e); // a = f 2^e, f in [0.5, 1)
-        const uint32_t m = (uint32_t)std::floor(std::ldexp(a, 11 - e)); // 11 significant bits
-        bits = ((uint32_t)(e + 14) << 10) + (m - 0x400u);
-    }
-    const float lo = rl_f16_value((uint16_t)bits);
-    if (lo != a) {
-        const float hi = rl_f16_value((uint16_t)(bits + 1u)); // (carries into the exponent where it should)
-        bool up;
-        if (round_up) up = !neg;          // towards +infinity: a positive value takes the larger magnitude
-        else {
-            const float dl = a - lo, dh = hi - a;
-            up = dh < dl || (dh == dl && (bits & 1u));
-        }
-        if (round_up && neg) up = false;  // towards +infinity: a negative value takes the smaller magnitude
-        if (up) bits += 1u;
-    }
-    return (uint16_t)((neg ? 0x8000u : 0u) | bits);
-}
-
 namespace {
 
 const float PI = RL_PI_F;
@@ -929,8 +889,8 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         const bool use_clusters = sph_in.size() >= 40;
         // ... but only a handful: every ray tests every direct sphere.  A scene whose radii are spread widely (the built-in
         // generator with 1,500 seeds: 1,213 of 4,511 spheres are more than four medians wide) used to put a quarter of its
-        // spheres here -- 72 % of the kernel's time (round 4, tools/kernel_stats.py) -- so beyond the RL_DIRECT_MAX largest the
-        // large ones are clustered like the rest (among themselves as far as the median cuts keep neighbours together).
+        // spheres here -- 72 % of the kernel's time (round 4, tools/kernel_stats.py: 1.8 Grays/s, 6.8 since) -- so beyond the
+        // RL_DIRECT_MAX largest the large ones are clustered like the rest.
         const size_t RL_DIRECT_MAX = 8;
         std::vector<std::pair<double, uint32_t>> large;
         for (uint32_t k = 0; k < sph_in.size(); ++k)
@@ -1084,43 +1044,6 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         const double c2 = (double)sp.x * sp.x + (double)sp.y * sp.y + (double)sp.z * sp.z;
         fs.sphere_cull_w[pos] = (float)(c2 - ((double)sp.w * 1.001 + 1.0e-6));
         fs.cull_cmax2 = std::max(fs.cull_cmax2, (float)c2 * 1.0001f);
-    }
-    // ... and the same balls in 8 bytes, relative to their cluster's bound centre (RlFlatScene::qmembers).
-    fs.qmembers.assign((size_t)fs.n_clusters * fs.cluster_k, 0);
-    fs.cluster_rmax2 = 0.0f;
-    for (uint32_t k = 0; k < fs.n_clusters; ++k) {
-        const RlF4 bc = fs.cull_bounds[k]; // the centre the kernel subtracts: the cull table's entry of cluster k
-        for (uint32_t j = 0; j < fs.cluster_k; ++j) {
-            const size_t pos = fs.cluster_base + (size_t)(fs.cluster_k + 1u) * k + 1u + j;
-            const RlF4& sp = fs.spheres[pos];
-            uint16_t h[4];
-            if (fs.sphere_obj[pos] == RL_HIT_NONE || !std::isfinite(sp.w) || !(sp.w >= 0.0f) || !std::isfinite(bc.x + bc.y + bc.z)) {
-                h[0] = h[1] = h[2] = rl_f16_bits(60000.0f, false); // padding: a point nothing reaches (the exact test would reject it anyway)
-                h[3] = 0;
-            } else {
-                const double local[3] = {(double)sp.x - (double)bc.x, (double)sp.y - (double)bc.y, (double)sp.z - (double)bc.z};
-                double moved2 = 0.0, reach2 = 0.0;
-                bool fits = true;
-                for (int a = 0; a < 3; ++a) {
-                    fits = fits && std::fabs(local[a]) <= 30000.0;
-                    h[a] = rl_f16_bits((float)local[a], false);
-                    const double q = (double)rl_f16_value(h[a]);
-                    moved2 += (q - local[a]) * (q - local[a]);
-                    reach2 += q * q;
-                }
-                const double radius = std::sqrt((double)sp.w * 1.001 + 1.0e-6) + std::sqrt(moved2) * 1.0001 + 1.0e-7;
-                fits = fits && radius <= 30000.0;
-                if (fits) {
-                    h[3] = rl_f16_bits((float)(radius * 1.0000002), true); // (the cast to float may round down by 2^-24)
-                    const double reach = std::sqrt(reach2) + (double)rl_f16_value(h[3]);
-                    fs.cluster_rmax2 = std::max(fs.cluster_rmax2, (float)(reach * reach * 1.0001));
-                } else { // too large for a half float: a ball that always passes (the exact test decides)
-                    h[0] = h[1] = h[2] = 0;
-                    h[3] = rl_f16_bits(65504.0f, false);
-                }
-            }
-            fs.qmembers[(size_t)k * fs.cluster_k + j] = (uint64_t)h[0] | ((uint64_t)h[1] << 16) | ((uint64_t)h[2] << 32) | ((uint64_t)h[3] << 48);
-        }
     }
     return RL_OK;
 }

@@ -95,12 +95,6 @@ struct RlFlatScene {
     std::vector<RlF4> prism_cyl;               // 2 records per prism {point on the axis, radius}, {unit axis, 0}; empty unless
     bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene
-    // The cluster members once more, 8 bytes each, for scenes whose 16-byte records do not fit LDS (RL_STAGE_HYBRID, rl_kernels.hip.h):
-    // {x, y, z, R} as four IEEE half floats RELATIVE TO THE CENTRE OF THE CLUSTER'S BOUND (cull_bounds[cluster].xyz), R rounded up and
-    // inflated by the distance the rounded centre moved: the ball {centre + (x, y, z), R} contains the sphere's cull ball
-    // (radius^2 * 1.001 + 1e-6).  n_clusters * cluster_k entries, cluster-major; padding slots hold a far-away point.
-    std::vector<uint64_t> qmembers;
-    float cluster_rmax2 = 0.0f;                // max over clusters of (|member centre - bound centre| + R)^2, rounded up: scales the local test's slack
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters, cluster_k; // see RlSceneView

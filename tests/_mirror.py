@@ -30,7 +30,6 @@ def lib():
         L.mirror_prism_cylinders.restype = u32
         L.mirror_prism_cylinders.argtypes = [vp, vp, u32]
         L.mirror_cull_counts.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
-        L.mirror_qmember_check.argtypes = [vp, u32, u32, u64, u32, u64, u64, vp]
         L.mirror_prism_pairs.restype = u64
         L.mirror_prism_pairs.argtypes = [vp, u64, u64, vp, vp, vp, u64]
         _lib = L
@@ -110,12 +109,3 @@ def cull_counts(scene, w, h, seed, stream, first, n):
     seg = float(c[0])
     return {"segments": int(c[0]), "groups": int(c[1]), "group_pairs": float(c[2]) / seg, "cluster_pairs": float(c[3]) / seg,
             "member_pairs": float(c[4]) / seg, "clusters": int(c[5]), "clusters_per_group": int(c[6]), "members_per_cluster": int(c[7])}
-
-
-def qmember_check(scene, w, h, seed, stream, first, n):
-    """mirror_qmember_check: the 8-byte cluster members (RL_STAGE_HYBRID) against the reference's sphere test on the segments of
-    paths [first, first + n).  Returns (segments, pairs the reference hits within the far bound, of those dropped by the 8-byte
-    test, pairs the 8-byte test passes, pairs the 16-byte test passes)."""
-    c = np.zeros(5, dtype=np.uint64)
-    lib().mirror_qmember_check(scene.h, w, h, seed, stream, first, n, O.ptr(c))
-    return tuple(int(v) for v in c)

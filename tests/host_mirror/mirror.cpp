@@ -410,88 +410,3 @@ extern "C" void mirror_cull_counts(void* scene, uint32_t w, uint32_t h, uint64_t
         }
     }
 }
-
-// ---- the 8-byte cluster members (RlFlatScene::qmembers, RL_STAGE_HYBRID) ---------------------------------------------------
-// The kernel's conservative member test in the cluster's frame, restated with the kernel's float operations (fused where the
-// kernel fuses; its approximate rsqrt is an exact one here -- the 0.999 in the scaled direction covers either), for the
-// segments of paths [first, first + n): a member the REFERENCE's sphere test hits (geometry.rs:204-240) not farther than the
-// nearest plane / circle / paraboloid hit -- the far bound the kernel's sphere pass starts with -- must pass.
-// out[0] segments, out[1] (member, ray) pairs the reference hits within the far bound, out[2] of those the 8-byte test
-// drops (must be 0), out[3] pairs the 8-byte test passes, out[4] pairs the 16-byte test (sphere_cull_w) passes.
-static float half_value(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
-    const float v = e == 0 ? ldexpf((float)m, -24) : ldexpf((float)(m | 0x400u), (int)e - 25);
-    return sign ? -v : v;
-}
-static float med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
-extern "C" void mirror_qmember_check(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first, uint64_t n, uint64_t* out) {
-    const MirrorScene* ms = (MirrorScene*)scene;
-    const RlSceneView& sv = ms->view;
-    const RlFlatScene& fs = ms->flat;
-    const float aspect = (float)w / (float)h;
-    for (int i = 0; i < 5; ++i) out[i] = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        RlPath p;
-        rl_begin_path(sv, aspect, seed, stream, first + i, &p);
-        float value = 0.0f;
-        for (;;) {
-            out[0] += 1;
-            RlSceneView small = sv;
-            small.n_direct = 0; small.n_clusters = 0; small.n_prisms = 0;
-            const RlHit near = rl_scan(small, p.origin, p.direction);
-            const RlF3 o = p.origin, dir = p.direction;
-            // rl_cull_ray
-            const float d2 = dir.x * dir.x + dir.y * dir.y + dir.z * dir.z;
-            const float inv = 1.0f / sqrtf(d2 * 0.999f);
-            const RlF3 D = rl_f3(dir.x * inv, dir.y * inv, dir.z * inv);
-            const RlF3 M = rl_f3(-2.0f * o.x, -2.0f * o.y, -2.0f * o.z);
-            const float o2g = o.x * o.x + o.y * o.y + o.z * o.z;
-            const float Pg = -(D.x * o.x + D.y * o.y + D.z * o.z);
-            const float Qg = 2.0e-5f * (o2g + fs.cull_cmax2) - o2g;
-            const float len = d2 * inv * 1.0001f;
-            const float far = near.t * len;
-            auto margin = [&](RlF3 d, float pp, RlF3 m, float q, RlF4 b) {
-                const float dd = fmaf(d.z, b.z, fmaf(d.y, b.y, fmaf(d.x, b.x, pp)));
-                const float cs = fmaf(m.z, b.z, fmaf(m.y, b.y, fmaf(m.x, b.x, b.w)));
-                const float x = med3f(dd, 0.0f, far);
-                return q - fmaf(x, fmaf(-2.0f, dd, x), cs);
-            };
-            for (uint32_t k = 0; k < fs.n_clusters; ++k) {
-                const RlF4 bc = fs.cull_bounds[k];
-                const RlF3 Ml = rl_f3(fmaf(2.0f, bc.x, M.x), fmaf(2.0f, bc.y, M.y), fmaf(2.0f, bc.z, M.z));
-                const float o2 = 0.25f * fmaf(Ml.z, Ml.z, fmaf(Ml.y, Ml.y, Ml.x * Ml.x));
-                const float Pl = 0.5f * fmaf(D.z, Ml.z, fmaf(D.y, Ml.y, D.x * Ml.x));
-                const float Ql = fmaf(2.0e-5f, o2 + fs.cluster_rmax2, -o2);
-                for (uint32_t j = 0; j < fs.cluster_k; ++j) {
-                    const size_t pos = sv.cluster_base + (size_t)(fs.cluster_k + 1u) * k + 1u + j;
-                    const uint64_t rec = fs.qmembers[(size_t)k * fs.cluster_k + j];
-                    RlF4 mb;
-                    mb.x = half_value((uint16_t)rec), mb.y = half_value((uint16_t)(rec >> 16)), mb.z = half_value((uint16_t)(rec >> 32));
-                    const float radius = half_value((uint16_t)(rec >> 48));
-                    mb.w = fmaf(mb.z, mb.z, fmaf(mb.y, mb.y, fmaf(mb.x, mb.x, -(radius * radius))));
-                    const bool pass8 = !std::signbit(margin(D, Pl, Ml, Ql, mb));
-                    RlF4 full = sv.spheres[pos];
-                    const float r2 = full.w;
-                    full.w = fs.sphere_cull_w[pos];
-                    const bool pass16 = !std::signbit(margin(D, Pg, M, Qg, full));
-                    out[3] += pass8 ? 1 : 0;
-                    out[4] += pass16 ? 1 : 0;
-                    if (fs.sphere_obj[pos] == RL_HIT_NONE) continue;
-                    // the reference's test (ring B of the kernel)
-                    const float cox = full.x - o.x, coy = full.y - o.y, coz = full.z - o.z;
-                    const float dd = dir.x * cox + dir.y * coy + dir.z * coz;
-                    const float c = (cox * cox + coy * coy + coz * coz) - r2;
-                    const float q = dd * dd - c;
-                    if (!(q >= 0.0f && dd > 0.0f)) continue;
-                    const float sq = sqrtf(q), t1 = dd - sq, t2 = dd + sq;
-                    if (!(t1 > 0.0f && t1 < t2) || !(t1 <= near.t)) continue;
-                    out[1] += 1;
-                    if (!pass8) out[2] += 1;
-                }
-            }
-            const RlHit hit = rl_scan(sv, p.origin, p.direction);
-            uint32_t emitter = 0;
-            if (rl_bounce(sv, seed, stream, first + i, &p, hit, &value, &emitter) != RL_PATH_CONTINUES) break;
-        }
-    }
-}

@@ -215,50 +215,6 @@ def test_planned_table_on_degenerate_sphere_layouts(layout):
         assert M.cull_counts(sm, 320, 180, 3, 0, 0, 200)["members_per_cluster"] in (10, 14)
 
 
-# ---- the 8-byte cluster members of the hybrid stage (RlFlatScene::qmembers) ------------------------------------------------
-
-@pytest.mark.parametrize("which,param,n", [(0, 0, 1500), (0, 158, 1200), (0, 1500, 150)])
-def test_eight_byte_members_never_drop_a_sphere_the_reference_hits(which, param, n):
-    """RL_STAGE_HYBRID (a scene too large for LDS) tests cluster members as 8-byte balls -- half-float centre relative to the
-    cluster's bound centre, radius rounded up by what the rounding moved -- in the cluster's frame.  A conservative pre-test
-    like the 16-byte form: whatever the reference's sphere arithmetic hits within the far bound must pass (0 dropped), on the
-    segments of real paths of the three built-in sphere scenes; and it must actually cull (pass fewer pairs than there are)."""
-    objs, cam = M.builtin_desc(which, param)
-    segments, hits, dropped, pass8, pass16 = M.qmember_check(M.Scene(objs, cam), 1280, 720, 5, 1, 0, n)
-    assert segments > n and hits > 100 and dropped == 0
-    n_spheres = int((objs["surface_kind"] == 0).sum())
-    assert pass8 < 0.05 * segments * n_spheres
-    assert pass8 <= pass16 * 1.05          # (the local frame's slack is the smaller one)
-
-
-@pytest.mark.parametrize("layout", ["same", "line", "zero_radius", "huge_spread", "far_away", "random"])
-def test_eight_byte_members_on_degenerate_sphere_layouts(layout):
-    """... and on sphere sets that strain the half floats: all at one point, on a line, radius zero, seven decades of spread
-    (centres and radii beyond the half range fall back to a ball that always passes), a cloud 30,000 units from the origin."""
-    objs0, cam = M.builtin_desc(0, 0)
-    proto = objs0[objs0["surface_kind"] == 0][:1]
-    rest = objs0[objs0["surface_kind"] != 0]
-    rng = np.random.default_rng(11)
-    for n in (41, 141):
-        o = np.repeat(proto, n)
-        o["v0"] = rng.normal(0, 8, (n, 3)).astype(np.float32)
-        o["v0"][:, 1] = np.abs(o["v0"][:, 1])
-        o["f"][:, 0] = rng.uniform(0.1, 1.0, n).astype(np.float32)
-        if layout == "same":
-            o["v0"] = np.array([1.0, 2.0, 3.0], np.float32)
-        elif layout == "line":
-            o["v0"] = np.stack([np.linspace(-20, 20, n), np.ones(n), np.ones(n)], 1).astype(np.float32)
-        elif layout == "zero_radius":
-            o["f"][:, 0] = 0.0
-        elif layout == "huge_spread":
-            o["v0"] = (rng.normal(0, 1, (n, 3)) * np.exp(rng.uniform(-5, 12, (n, 1)))).astype(np.float32)
-            o["f"][:, 0] = np.exp(rng.uniform(-8, 3, n)).astype(np.float32)
-        elif layout == "far_away":
-            o["v0"] += np.array([30000.0, 12345.0, -7000.0], np.float32)
-        segments, hits, dropped, pass8, pass16 = M.qmember_check(M.Scene(np.concatenate([rest, o]), cam), 320, 180, 3, 0, 0, 600)
-        assert dropped == 0, (layout, n, hits, dropped)
-
-
 # ---- the prism shortcut (rl_hex_prism_fast) against the Compound tree it stands in for (geometry.rs:380-407) ----------
 
 @pytest.mark.parametrize("which", [0, 1])
