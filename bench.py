@@ -209,6 +209,9 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
         "active_lanes": lanes,
         "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
         "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
+        # occupancy actually achieved: wave-cycles (a quad-cycle counter) per elapsed cycle and SIMD.  The compiler reports 118-120
+        # VGPRs for this kernel, rocprofv3 "VGPR_Count 60" (the unified file counted in halves): 4 waves per SIMD either way.
+        "resident_waves_per_simd": (4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / simds) if c.get("SQ_WAVE_CYCLES") else None,
         # SQ_LDS_BANK_CONFLICT counts LDS-array cycles (one per extra address on a busy bank), summed over the CUs; GRBM_GUI_ACTIVE is
         # summed over the 8 XCDs: conflict cycles per CU-cycle = the share of time a CU's LDS spends on conflicts (round 3 divided
         # by SQ_ACTIVE_INST_LDS, a quad-cycle counter of something else -- VERDICT r03).  Attribution: profiles/r04_lds_conflicts.txt.
@@ -295,6 +298,7 @@ def executed_live(args, committed, timeout_s=100.0):
         "active_lanes": lanes,
         "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
         "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
+        "resident_waves_per_simd": 4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / 1024.0,
         "wave_time": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                       "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
         "lds_bank_conflict_cycles_per_cu_cycle": c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0),

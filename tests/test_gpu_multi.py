@@ -251,6 +251,9 @@ def test_bench_line_counts_its_own_counters_when_rocprofv3_is_on_the_box():
     assert 0.6 < live["active_lanes"] < 1.0 and 0.3 < live["useful_lane_slots_vs_2cyc"] < 0.8
     assert abs(sum(live["wave_time"].values()) - 1.0) < 0.15
     assert live["seconds"] < 100
+    # the occupancy the design leans on, from the counters: a resident trace kernel holds 4 waves per SIMD (the
+    # compiler reports 118-120 VGPRs, rocprofv3 "VGPR_Count 60" -- the unified register file counted in halves)
+    assert 3.5 < live["resident_waves_per_simd"] <= 4.02
 
 
 def test_bench_with_more_ranks_than_gpus_falls_back_instead_of_hanging(R):

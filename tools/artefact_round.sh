@@ -6,15 +6,16 @@
 #   with two ranks sharing the GPU, the VALU microbenchmark.  ~8 minutes.
 # Usage (through gpurun): bash tools/artefact_round.sh r02   -> then tools/install_artefacts.sh r02 here.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_console.txt 2>&1
 (timeout 300 python tools/image_parity.py 1280 720 32 demo; timeout 300 python tools/image_parity.py 1920 1080 16 demo
  timeout 300 python tools/image_parity.py 1280 720 16 glass) > $OUT/image_parity.txt 2>&1
-for s in demo glass replicated; do timeout 120 python tools/kernel_stats.py 64 $s; done > $OUT/kernel_stats.txt 2>&1
+for s in demo glass replicated spill; do timeout 120 python tools/kernel_stats.py 64 $s; done > $OUT/kernel_stats.txt 2>&1
 (timeout 1200 python tools/big_parity.py 256 demo; timeout 500 python tools/big_parity.py 96 glass
- timeout 500 python tools/big_parity.py 128 replicated; timeout 900 python tools/random_scene_sweep.py 1000) > $OUT/big_parity.txt 2>&1
+ timeout 500 python tools/big_parity.py 128 replicated; timeout 900 python tools/random_scene_sweep.py 1000
+ timeout 900 python tools/random_scene_sweep.py 100 32768 big) > $OUT/big_parity.txt 2>&1
 python - > $OUT/app.txt <<'PY'
 import robigo_luculenta_amd as R
 print("rl_app_run, built-in scene, 1280x720, 4096 batches of 524288 paths (trace_unit.rs:67), seconds include the final tonemap")
@@ -35,8 +36,10 @@ print("fused, two ranks on one GPU (devices = [0, 0]), workers 4", round(st["sec
 PY
 (echo '$ python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64   # two ranks share GPU 0'
  timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64) > $OUT/bench_2ranks_gloo.txt 2>&1
-(echo '$ python bench.py --gpus 1 --dist-backend rccl  (one rank; for comparison)'; timeout 300 python bench.py --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-others --no-cpu-baseline) >> $OUT/bench_2ranks_gloo.txt 2>&1
+(echo '$ python bench.py --gpus 1 --dist-backend rccl  (one rank; for comparison)'; timeout 300 python bench.py --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-others --no-cpu-baseline --no-live-counters) >> $OUT/bench_2ranks_gloo.txt 2>&1
 timeout 300 python tools/open_launch_stress.py > $OUT/open_launch_stress.txt 2>&1
 timeout 900 tools/valu_mb > $OUT/valu_microbench.txt 2>&1
+bash tools/lds_conflicts.sh $TAG > /dev/null 2>&1
+bash tools/pmc_stalls.sh $TAG demo-1080p > $OUT/instruction_mix.txt 2>&1; bash tools/pmc_stalls.sh $TAG glass-720p >> $OUT/instruction_mix.txt 2>&1
 cat $OUT/app.txt $OUT/big_parity.txt $OUT/image_parity.txt
 tail -12 gpurun_out/${TAG}_console.txt | cut -c1-400

@@ -17,6 +17,8 @@ cp $SRC/big_parity.txt profiles/${TAG}_big_parity.txt
 cp $SRC/bench_2ranks_gloo.txt profiles/${TAG}_bench_2ranks_gloo.txt
 cp $SRC/valu_microbench.txt profiles/${TAG}_valu_microbench.txt
 cp $SRC/open_launch_stress.txt profiles/${TAG}_open_launch_stress.txt
+[ -f $SRC/lds_conflicts.txt ] && cp $SRC/lds_conflicts.txt profiles/${TAG}_lds_conflicts.txt
+[ -f $SRC/instruction_mix.txt ] && cp $SRC/instruction_mix.txt profiles/${TAG}_instruction_mix.txt
 [ -f $SRC/app_soak.txt ] && cp $SRC/app_soak.txt profiles/${TAG}_app_soak.txt
 python - "$TAG" <<'PY'
 import json, sys

@@ -6,7 +6,7 @@ TAG=${1:-ic}; CFG=${2:-demo-1080p}; shift; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-cpu-baseline --no-others --config $CFG $*"
+ARGS="--steps 1 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-cpu-baseline --no-others --no-live-counters --config $CFG $*"
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -f csv -d $OUT/ic_$CFG -o p -- python bench.py $ARGS > $OUT/ic_$CFG.log 2>&1
 python - <<PY
 import csv, collections

@@ -6,7 +6,7 @@ TAG=${1:-q}; CFG=${2:-demo-1080p}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-cpu-baseline --no-others --config $CFG"
+ARGS="--steps 1 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-cpu-baseline --no-others --no-live-counters --config $CFG"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS -f csv -d $OUT/st1_$CFG -o p -- python bench.py $ARGS > $OUT/st1_$CFG.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_BUSY_CYCLES -f csv -d $OUT/st2_$CFG -o p -- python bench.py $ARGS > $OUT/st2_$CFG.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_FMA_F32 -f csv -d $OUT/st3_$CFG -o p -- python bench.py $ARGS > $OUT/st3_$CFG.log 2>&1

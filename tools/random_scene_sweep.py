@@ -2,7 +2,8 @@
 """Bit-exact parity over many random scenes (tests/_random_scene.py: arbitrary mixes of every surface and material
 kind, nested / overlapping / huge spheres, randomly oriented prisms), both primitive-fetch modes: exercises the
 conservative culls (sphere clusters, prism bounds) far away from the built-in scenes' regular layouts.
-Usage (GPU box): python tools/random_scene_sweep.py [scenes=200] [photons=262144]"""
+Usage (GPU box): python tools/random_scene_sweep.py [scenes=200] [photons=262144] [big]
+"big": 2,000 - 8,000 spheres per scene -- too large for LDS, every record from global memory (VERDICT r03 #2).  """
 import os
 import sys
 import time
@@ -18,6 +19,7 @@ from _random_scene import random_scene  # noqa: E402
 
 scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 18
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 threads = max(1, len(os.sched_getaffinity(0)))
 try:
     q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -29,7 +31,7 @@ rng = np.random.default_rng(2024)
 bad, rays, t0 = 0, 0, time.time()
 sizes = []
 for k in range(scenes):
-    n_spheres = int(rng.choice([3, 9, 25, 39, 40, 41, 77, 130, 200, 333, 512, 800]))
+    n_spheres = int(rng.choice([2000, 2500, 3000, 4000, 5000, 6500, 8000] if BIG else [3, 9, 25, 39, 40, 41, 77, 130, 200, 333, 512, 800]))
     n_prisms = int(rng.choice([0, 0, 1, 2, 5, 9, 17, 30, 45, 80]))   # from 40 on: the prisms' second bound (CYL kernels)
     objs, cam = random_scene(1000 + k, n_spheres=n_spheres, n_prisms=n_prisms, n_planes=int(rng.integers(0, 4)),
                              n_circles=int(rng.integers(0, 4)), n_parabs=int(rng.integers(0, 3)))
@@ -38,7 +40,7 @@ for k in range(scenes):
     want, segs = oscene.render(640, 360, 1000 + k, k % 7, 10_000_000 * k, N, threads=threads)
     rays += segs
     sizes.append(len(objs))
-    for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+    for fetch in ((R.FETCH_LDS,) if BIG else (R.FETCH_LDS, R.FETCH_GLOBAL)):   # (a big scene spills to global fetch by itself)
         t = R.TraceUnit(0, 640, 360, n_photons=N)
         t.set_fetch(fetch)
         if k % 2 == 0:   # an open launch (the blocking call) / a plain launch of its own: the two kernel variants
@@ -49,5 +51,5 @@ for k in range(scenes):
         if t.mapped_photons.tobytes() != want.tobytes() or t.stats()[1] != segs:
             bad += 1
             print("MISMATCH scene", k, "spheres", n_spheres, "prisms", n_prisms, "fetch", fetch)
-print("%d random scenes (%d..%d objects), %d photons each, both fetch modes: %d rays checked, %d mismatching renders, %.1f s"
-      % (scenes, min(sizes), max(sizes), N, 2 * rays, bad, time.time() - t0))
+print("%d random scenes (%d..%d objects), %d photons each, %s: %d rays checked, %d mismatching renders, %.1f s"
+      % (scenes, min(sizes), max(sizes), N, "spilled to global fetch" if BIG else "both fetch modes", (1 if BIG else 2) * rays, bad, time.time() - t0))
