@@ -1011,6 +1011,7 @@ void oracle_math_f32(int fn, const float* x, float* y, uint64_t n) {
         case 9: y[i] = rl_cosf_d(x[i]); break;
         case 10: y[i] = rl_expf_d(x[i]); break;
         case 11: y[i] = rl_acosf_d(x[i]); break;
+        case 12: y[i] = Sf10GlassMaterial::get_index_of_refraction(x[i]); break; // material.rs:203-213 (the oracle's own restatement)
         default: y[i] = 0.0f;
         }
     }

@@ -132,9 +132,34 @@ struct RlHit {
     uint32_t sub; // prism: which of the 8 half-spaces
 };
 
-// material.rs:203-213
+// material.rs:203-213.  The reference evaluates the Sellmeier sum in f64 -- three divisions and a square root, ~100 f64
+// operations on this chip, once per path -- and rounds to f32.  On the GPU the same f32 is DECIDED from a cheaper evaluation
+// whenever it can be: the three fractions over one denominator, reciprocal and inverse square root from the hardware's
+// approximations refined by two Newton steps each (~40 operations, relative error far below 2^-40; the reference's own
+// rounding errors are ~2^-51), accepted only if every value within 2^-40 of it rounds to the same float -- then the reference's
+// double does too.  Otherwise (one wavelength in ~10^4 is that close to a rounding boundary; NaN, infinities and a zero
+// denominator never compare equal) the wave evaluates the reference's expression.  Checked against it for EVERY f32 wavelength of
+// [380, 780] and a range of others on the device (tests/test_gpu_parity.py).
 RL_HD float rl_sf10_ior(float wavelength) {
     const double w2 = (double)(wavelength * wavelength * 1.0e-6f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        const double t1 = w2 - 0.0131887070, t2 = w2 - 0.0623068142, t3 = w2 - 155.23629000;
+        const double t23 = t2 * t3, t13 = t1 * t3, t12 = t1 * t2;
+        const double num = __builtin_fma(1.737596950 * w2, t23, __builtin_fma(0.313747346 * w2, t13, (1.898781010 * w2) * t12));
+        const double den = t1 * t23;
+        double y = __builtin_amdgcn_rcp(den);
+        y = __builtin_fma(y, __builtin_fma(-den, y, 1.0), y);
+        y = __builtin_fma(y, __builtin_fma(-den, y, 1.0), y);
+        const double sum = 1.0 + num * y;
+        double r = __builtin_amdgcn_rsq(sum);
+        r = __builtin_fma(0.5 * r, __builtin_fma(-(sum * r), r, 1.0), r);
+        r = __builtin_fma(0.5 * r, __builtin_fma(-(sum * r), r, 1.0), r);
+        const double n = sum * r;
+        const float lo = (float)(n * (1.0 - 9.094947017729282e-13)), hi = (float)(n * (1.0 + 9.094947017729282e-13)); // 2^-40
+        if (__builtin_amdgcn_ballot_w64(!(lo == hi)) == 0) return lo;
+    }
+#endif
     return (float)sqrt(1.0 + 1.737596950 * w2 / (w2 - 0.0131887070) + 0.313747346 * w2 / (w2 - 0.0623068142) +
                        1.898781010 * w2 / (w2 - 155.23629000));
 }

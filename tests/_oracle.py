@@ -151,7 +151,7 @@ def tonemap(xyz, w, h):
 
 
 def math_f32(fn, x):
-    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "closed01": 6, "halfopen01": 7, "sin_d": 8, "cos_d": 9, "exp_d": 10, "acos_d": 11}
+    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "closed01": 6, "halfopen01": 7, "sin_d": 8, "cos_d": 9, "exp_d": 10, "acos_d": 11, "sf10": 12}
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.zeros_like(x)
     lib().oracle_math_f32(names[fn], ptr(x), ptr(y), x.size)

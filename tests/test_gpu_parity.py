@@ -80,6 +80,23 @@ def test_ieee_sqrt_div_and_f64_islands_on_device():
     assert R.math_probe("gamma", g).tobytes() == wantg.tobytes()
 
 
+def test_sf10_index_decided_from_the_cheap_evaluation_is_the_reference_f64_expression_for_every_wavelength():
+    """material.rs:203-213 in f64, rounded to f32.  The kernel decides that f32 from a cheaper evaluation (one division, Newton
+    steps on the hardware's reciprocal / inverse square root) whenever everything within 2^-40 of it rounds to the same float,
+    and evaluates the reference's expression otherwise (rl_sf10_ior, rl_core.h): the result must be the oracle's for EVERY f32
+    wavelength of the visible range [380, 780] (8.7 M values) and for a sweep of others, zero, negatives, infinities and NaN included."""
+    lo, hi = np.float32(380.0).view(np.uint32), np.float32(780.0).view(np.uint32)
+    lam = np.arange(int(lo), int(hi) + 1, dtype=np.uint32).view(np.float32)
+    assert lam.size > 8_000_000 and lam[0] == 380.0 and lam[-1] == 780.0
+    odd = np.concatenate([np.exp(np.linspace(-20, 20, 200001)).astype(np.float32), -np.linspace(0, 2000, 4001).astype(np.float32),
+                          np.array([0.0, 114.84, 114.85, 249.6, 249.62, 12459.38, 12459.4, np.inf, -np.inf, np.nan], np.float32)])
+    for x in (lam, odd):
+        got = R.math_probe("sf10", x)
+        with np.errstate(all="ignore"):
+            want = O.math_f32("sf10", x)
+        assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
+
+
 def test_normalise_with_the_shared_reciprocal_is_the_ieee_division_bit_for_bit():
     """rl_normalise (vector3.rs:56-67) divides three components by one length; on the device the reciprocal's refinement is
     shared and the scaling / fix-up steps of the compiler's division are skipped where they pass their operands through
