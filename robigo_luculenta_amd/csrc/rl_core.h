@@ -44,8 +44,31 @@ RL_HD float rl_dot(RlF3 a, RlF3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                                                // vector3.rs:27-33
     return rl_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// The IEEE square root (f32::sqrt of the reference: geometry.rs:217,326, material.rs:244, monte_carlo.rs:53-57, vector3.rs:52).
+// The compiler's correctly rounded expansion is 16 instructions, half of them in the half-rate classes (scale the argument out
+// of the denormal range and back, the hardware's 1-ulp root, two neighbours tried by residual, a class fix-up).  On gfx950
+//     y = v_rsq_f32(x);  s = x y;  h = y / 2;  s + (x - s s) h      (two products, two fused multiply-adds)
+// IS that root for every normal x >= 2^-96 -- not argued: tools/sqrt_exhaustive.hip compares the two for all 1,879,048,192
+// such floats on the device (0 differ; the hardware root alone differs for 284 M of them), and
+// test_short_square_root_is_the_ieee_one_for_every_normal_float repeats it through the library.  Arguments outside that range
+// (zero, denormals and the smallest normals, infinity, NaN, negative numbers) make the WAVE take the compiler's form.
+// magnitude_only: the caller discards the root of a negative argument (the paraboloid's discriminant), so |x| is rooted instead
+// and negative arguments do not cost the wave its short form.
+RL_HD float rl_sqrtf(float x, bool magnitude_only = false) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float a = magnitude_only ? fabsf(x) : x;
+    const bool in_range = rl_f2u(a) - 0x0f800000u < 0x7f800000u - 0x0f800000u; // 2^-96 <= a < infinity
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+        const float y = __builtin_amdgcn_rsqf(a);
+        const float s = a * y, h = 0.5f * y;
+        return __builtin_fmaf(__builtin_fmaf(-s, s, a), h, s);
+    }
+#endif
+    return sqrtf(x);
+}
+
 RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
-    const float m = sqrtf(rl_dot(v, v));
+    const float m = rl_sqrtf(rl_dot(v, v));
 #if defined(__HIP_DEVICE_COMPILE__)
     // Three IEEE divisions by the same m.  The compiler's division is v_div_scale x 2, v_rcp, a refinement of the
     // reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup (11 instructions, 33 for a vector).
@@ -270,7 +293,7 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     // numerator is so small that half of it is no float (|n| < 2^-125, 0 excepted); those waves, and the ones holding a
     // ray with a >= 0 or a NaN, take the literal form below (wave-uniform).
     const float disc = b * b - 4.0f * a * c;
-    const float sq = sqrtf(disc);
+    const float sq = rl_sqrtf(disc, true); // (a negative discriminant is a miss whatever `sq` is)
     const float np = -b + sq, nq = -b - sq;
     const float pick = np < 0.0f ? np : nq;
     const bool plain = a < 0.0f && (disc < 0.0f || ((fabsf(np) >= 1.0e-37f || np == 0.0f) && (fabsf(nq) >= 1.0e-37f || nq == 0.0f)));
@@ -725,7 +748,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         if (sin_t_sqr > 1.0f) {
             new_dir = mirrored;
         } else {
-            const float cos_t = sqrtf(1.0f - sin_t_sqr);
+            const float cos_t = rl_sqrtf(1.0f - sin_t_sqr);
             new_dir = rl_add(rl_mul(in_dir, ior), rl_mul(normal, ior * cos_i - cos_t));
         }
         probability = 1.0f;
@@ -740,6 +763,10 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         const bool soap = material_kind == RL_MATERIAL_SOAP_BUBBLE;
         const RlF3 facing = (rl_dot(in_dir, is.normal) < 0.0f) ? is.normal : rl_neg(is.normal);
         RlF3 axis = rl_cross(rl_f3(0.0f, 0.0f, 1.0f), facing);
+        // (rotate_towards returns before it looks at its first axis when |n.z| > 0.9999, vector3.rs:73-76: give those lanes -- every
+        // hit on a horizontal plane, whose cross product is the zero vector -- a unit vector, so that the normalisation below
+        // keeps its short form for the wave instead of falling back for a result nobody reads)
+        if (fabsf(facing.z) > 0.9999f) axis = rl_f3(1.0f, 0.0f, 0.0f);
         if (soap) axis = surface_kind == RL_SURFACE_SPHERE ? rl_cross(rl_f3(0.0f, 1.0f, 0.0f), is.normal) : rl_f3(0.0f, 0.0f, 0.0f);
         const RlF3 unit_axis = rl_normalise(axis);
         float angle;
@@ -768,8 +795,8 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
             probability = cos_a * 0.1f + 0.9f;
         } else { // the diffuse family: material.rs:38-58 then :122-130 / :155-168 / :185-196
             const float rq = rl_get_unit(rb.w[1]);
-            const float r = sqrtf(rq);
-            const RlF3 hemi = rl_f3(cos_a * r, sin_a * r, sqrtf(1.0f - rq));
+            const float r = rl_sqrtf(rq);
+            const RlF3 hemi = rl_f3(cos_a * r, sin_a * r, rl_sqrtf(1.0f - rq));
             new_dir = rl_rotate_towards(hemi, facing, unit_axis);
             probability = 1.0f;
             if (material_kind == RL_MATERIAL_DIFFUSE_GREY) {

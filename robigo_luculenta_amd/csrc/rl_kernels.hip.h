@@ -369,10 +369,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             const float dd = dx * cox + dy * coy + dz * coz;
             const float c = (cox * cox + coy * coy + coz * coz) - sv.sphere_r2[pos]; // (a clustered sphere's s.w is its cull term)
             const float q = dd * dd - c;
-            const float sq = sqrtf(q);
+            const float sq = rl_sqrtf(q, true); // |q| is rooted: a miss of the pre-tested pair (q < 0, geometry.rs:213-215) is tested for itself
             const float t1 = dd - sq;
             const float t2 = dd + sq;
-            if (t1 > 0.0f && t1 < t2) {
+            if (q >= 0.0f && t1 > 0.0f && t1 < t2) {
                 const uint32_t obj = sv.sphere_obj[pos];
                 __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)(obj << 3),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1365,6 +1365,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __res
 // 10: rl_roulette_ends(unit = x[i], continue_chance = x[m + i], intensity = x[2m + i]) for i < m = n / 3 (1 or 0)
 // 11: rl_normalise((x[i], x[m + i], x[2m + i])) -> (y[i], y[m + i], y[2m + i])
 // 12 sin 13 cos 14 exp 15 acos in their f64-evaluated forms (rl_*_d: scene construction, out-of-domain arguments)
+// 16: rl_sqrtf (the short form where the whole wave's arguments allow it)
 __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float* __restrict__ y, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (fn == 10) { // whole waves take part: the fast path is a wave-uniform decision
@@ -1393,6 +1394,7 @@ __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float*
     case 7: r = sqrtf(v); break;
     case 8: r = v / x[(i + 1) % n]; break;
     case 9: r = rl_powf(v, 1.0f / 2.4f); break;
+    case 16: r = rl_sqrtf(v); break;
     case 12: r = rl_sinf_d(v); break;
     case 13: r = rl_cosf_d(v); break;
     case 14: r = rl_expf_d(v); break;
