@@ -46,6 +46,8 @@ CONFIGS = {
     # ablation scenes (not BASELINE configs): prefixes of the demo scene's object list
     "ablate-noprisms": ("demo[:317]", 0, 1920, 1080),
     "ablate-fixed7": ("demo[:7]", 0, 1920, 1080),
+    "ablate-empty": ("demo[:0]", 0, 1920, 1080),      # no object: every path is one segment into the Void (refill + loop overhead)
+    "ablate-sun": ("demo[:1]", 0, 1920, 1080),        # the sun alone
     "ablate-seeds": ("demo[:207]", 0, 1920, 1080),
     "ablate-allgrey": ("demo[grey]", 0, 1920, 1080),  # every reflective material -> DiffuseGrey(0.8)
 }

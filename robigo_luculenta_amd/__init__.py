@@ -408,7 +408,7 @@ def variant_launches():
 
 def math_probe(fn, x, device=0):
     """Evaluates csrc/rl_math.h function `fn` on the GPU (diagnostics for the parity tests)."""
-    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10, "normalise": 11, "sin_d": 12, "cos_d": 13, "exp_d": 14, "acos_d": 15, "sqrt_short": 16}
+    names = {"sin": 0, "cos": 1, "tan": 2, "exp": 3, "log": 4, "acos": 5, "sf10": 6, "sqrt": 7, "div": 8, "gamma": 9, "roulette": 10, "normalise": 11, "sin_d": 12, "cos_d": 13, "exp_d": 14, "acos_d": 15, "sqrt_short": 16, "recip_short": 17, "div200_short": 18}
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.zeros_like(x)
     check(lib.rl_debug_math_probe(device, names[fn], x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size))

@@ -67,24 +67,54 @@ RL_HD float rl_sqrtf(float x, bool magnitude_only = false) {
     return sqrtf(x);
 }
 
-RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
-    const float m = rl_sqrtf(rl_dot(v, v));
+// Two one-operand IEEE divisions in three operations each, where the wave's arguments are normal floats with 2^-100 <= |x| < 2^100
+// (else the compiler's 11-instruction division): 1 / x = y + (1 - x y) y with y = v_rcp_f32(x) (material.rs:224), and
+// x / 200 = q + (x - 200 q) c with c = fl(1 / 200), q = x c (material.rs:283, camera.rs:100).  Like rl_sqrtf's short form these ARE
+// the correctly rounded quotients for every such float of either sign on gfx950 -- tools/sqrt_exhaustive.hip compares all
+// 3,355,443,200 of them with the compiler's divisions (0 differ), and the GPU tests repeat it through the library.
+RL_HD float rl_recipf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Three IEEE divisions by the same m.  The compiler's division is v_div_scale x 2, v_rcp, a refinement of the
-    // reciprocal, the quotient with two residual corrections, v_div_fmas, v_div_fixup (11 instructions, 33 for a vector).
+    const bool in_range = (rl_f2u(x) & 0x7fffffffu) - 0x0d800000u < 0x71800000u - 0x0d800000u;
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+        const float y = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
+    }
+#endif
+    return 1.0f / x;
+}
+RL_HD float rl_div200f(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool in_range = (rl_f2u(x) & 0x7fffffffu) - 0x0d800000u < 0x71800000u - 0x0d800000u;
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+        const float c = 0.005f, q = x * c;
+        return __builtin_fmaf(__builtin_fmaf(-200.0f, q, x), c, q);
+    }
+#endif
+    return x / 200.0f;
+}
+
+RL_HD RlF3 rl_normalise(RlF3 v) {                                                                    // vector3.rs:56-67
+    const float d2 = rl_dot(v, v);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The square root in its short form (rl_sqrtf) and three IEEE divisions by the same m.  The compiler's division is
+    // v_div_scale x 2, v_rcp, a refinement of the reciprocal, the quotient with two residual corrections, v_div_fmas,
+    // v_div_fixup (11 instructions, 33 for a vector).
     // Everything that depends on the divisor alone is shared here, and the scaling / fix-up steps are left out where
     // they do nothing: v_div_scale passes its operands through and v_div_fixup its quotient when the divisor is a normal
     // number far from the ends of the range and the numerator is zero or not tiny against it (the conditions below,
     // from the instruction's definition).  What remains is the very same sequence of correctly rounded operations --
     // rcp, e = fma(-m, y, 1), y = fma(e, y, y), q = x y, r = fma(-m, q, x), q = fma(r, y, q), r = fma(-m, q, x),
     // q = fma(r, y, q) -- so the quotients are the compiler's bit for bit (the parity tests compare them with the g++
-    // build's divisions); a zero keeps its sign.  Any other operand in the wave: the plain divisions below.
+    // build's divisions); a zero keeps its sign.  Any other operand in the wave: the plain forms below.
     const uint32_t bx = rl_f2u(v.x) & 0x7fffffffu, by = rl_f2u(v.y) & 0x7fffffffu, bz = rl_f2u(v.z) & 0x7fffffffu;
     uint32_t least = bx - 1u < by - 1u ? bx - 1u : by - 1u; // (0 - 1 wraps to the largest value: zeros pass)
     least = bz - 1u < least ? bz - 1u : least;
     const bool plain = least >= 0x1f800000u - 1u                         // every component is 0 or at least 2^-64
-                       && rl_f2u(m) - 0x21800000u < 0x5d800000u - 0x21800000u; // 2^-60 <= m < 2^60 (NaN and 0 fail)
+                       && rl_f2u(d2) - 0x0f800000u < 0x7a800000u - 0x0f800000u; // 2^-96 <= |v|^2 < 2^118: 2^-48 <= m < 2^59 (NaN and 0 fail)
     if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+        const float ys = __builtin_amdgcn_rsqf(d2);
+        const float s = d2 * ys, h = 0.5f * ys;
+        const float m = __builtin_fmaf(__builtin_fmaf(-s, s, d2), h, s); // = sqrtf(d2), see rl_sqrtf
         float y = __builtin_amdgcn_rcpf(m);
         y = __builtin_fmaf(__builtin_fmaf(-m, y, 1.0f), y, y);
         auto quotient = [&](float x) {
@@ -96,6 +126,7 @@ RL_HD RlF3 rl_normalise(RlF3 v) {                                               
         return rl_f3(quotient(v.x), quotient(v.y), quotient(v.z));
     }
 #endif
+    const float m = sqrtf(d2);
     const RlF3 u = rl_f3(v.x / m, v.y / m, v.z / m); // inf/NaN for m == 0, discarded below
     return (m == 0.0f) ? v : u;
 }
@@ -223,7 +254,7 @@ RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t see
     const RlRngBlock b1 = rl_rng_block(seed, stream, path, 1);
     const float dof_angle = rl_get_longitude(b1.w[0]);
     const float dof_radius = rl_get_unit(b1.w[1]) / cd.depth_of_field;
-    const float d = (wavelength - 580.0f) / 200.0f;
+    const float d = rl_div200f(wavelength - 580.0f);
     const float zoom = 1.0f + d * cd.chromatic_abberation;
 
     // Camera::get_screen_ray
@@ -739,7 +770,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         float ior = p->ior;
         RlF3 normal = is.normal;
         if (cos_i > 0.0f) {
-            ior = 1.0f / ior;
+            ior = rl_recipf(ior);
         } else {
             normal = rl_neg(normal);
             cos_i = -cos_i;
@@ -784,7 +815,7 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
         float acos_phi, acos_theta;
         rl_acos_pair(soap, cos_phi, cos_theta, pair_scratch, &acos_phi, &acos_theta);
         if (soap) {
-            const float phase_shift = (p->wavelength - 380.0f) / 200.0f * RL_PI_F;
+            const float phase_shift = rl_div200f(p->wavelength - 380.0f) * RL_PI_F;
             angle = phase_shift - acos_phi * 3.0f - acos_theta * 2.0f + RL_PI_F * 0.5f;
         } else {
             angle = rl_get_longitude(rb.w[0]); // monte_carlo.rs:47-58

@@ -409,20 +409,21 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     if (n_direct != 0) {
         const uint32_t full = n_direct & ~3u;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
-        for (uint32_t i = 0; i < full; i += 4) {
-            const RlF4 n0 = sph[i + 4], n1 = sph[i + 5], n2 = sph[i + 6], n3 = sph[i + 7];
+        for (uint32_t i = 0; i < full; i += 4) { // (each record is re-loaded in place once it has been tested: no copies, see RL_GROUP_CULLS)
             RL_SPHERE_REJECT(c0, i, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            c0 = sph[i + 4];
             RL_SPHERE_REJECT(c1, i + 1, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            c1 = sph[i + 5];
             RL_SPHERE_REJECT(c2, i + 2, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+            c2 = sph[i + 6];
             RL_SPHERE_REJECT(c3, i + 3, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            c3 = sph[i + 7];
         }
         for (uint32_t i = full; i < n_direct; ++i) {
-            const RlF4 next = sph[i + 1];
             uint32_t pos = i; // opaque: (full << 6) | lane is loop-invariant over the PERSISTENT loop too, gets hoisted out of
             asm volatile("" : "+s"(pos)); // it into a vector register that lives through the whole kernel -- and spills
             RL_SPHERE_REJECT(c0, pos, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
-            c0 = next;
+            c0 = sph[i + 1];
         }
     }
     RL_T1(RL_ST_T_DIRECT, t_direct);
@@ -556,9 +557,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
         RlF4 g0 = gb[0];                                                                                \
         for (uint32_t g = 0; g < (N_GROUPS); ++g) {                                                     \
-            const RlF4 g1 = gb[g + 1]; /* prefetch (the table has slack at its end) */                  \
             const bool pass = rl_cull_pass(cr, g0, far);                                                \
             const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
+            /* the next bound goes into the registers this one has just left (the table has slack at its end): loaded one   \
+               test ahead into registers of its own it had to be COPIED over g0 every time round -- four moves and an address \
+               per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
+            g0 = gb[g + 1];                                                                             \
             if (m != 0) {                                                                               \
                 if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (g << 6) | lane; /* group number within its kind */ \
                 s_tail += (uint32_t)__popcll(m);                                                        \
@@ -567,7 +571,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                     s_head += 64u;                                                                      \
                 }                                                                                       \
             }                                                                                           \
-            g0 = g1;                                                                                    \
         }                                                                                               \
         if (s_tail != s_head) {                                                                         \
             const uint32_t left = s_tail - s_head;                                                      \
@@ -1365,7 +1368,7 @@ __global__ __launch_bounds__(RL_BLOCK) void rl_tonemap_kernel(const float* __res
 // 10: rl_roulette_ends(unit = x[i], continue_chance = x[m + i], intensity = x[2m + i]) for i < m = n / 3 (1 or 0)
 // 11: rl_normalise((x[i], x[m + i], x[2m + i])) -> (y[i], y[m + i], y[2m + i])
 // 12 sin 13 cos 14 exp 15 acos in their f64-evaluated forms (rl_*_d: scene construction, out-of-domain arguments)
-// 16: rl_sqrtf (the short form where the whole wave's arguments allow it)
+// 16: rl_sqrtf, 17: rl_recipf, 18: rl_div200f (their short forms where the whole wave's arguments allow them)
 __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float* __restrict__ y, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (fn == 10) { // whole waves take part: the fast path is a wave-uniform decision
@@ -1395,6 +1398,8 @@ __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float*
     case 8: r = v / x[(i + 1) % n]; break;
     case 9: r = rl_powf(v, 1.0f / 2.4f); break;
     case 16: r = rl_sqrtf(v); break;
+    case 17: r = rl_recipf(v); break;
+    case 18: r = rl_div200f(v); break;
     case 12: r = rl_sinf_d(v); break;
     case 13: r = rl_cosf_d(v); break;
     case 14: r = rl_expf_d(v); break;

@@ -119,6 +119,30 @@ def test_short_square_root_is_the_ieee_one_for_every_normal_float():
     assert np.array_equal(got.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
 
 
+@pytest.mark.parametrize("fn", ["recip_short", "div200_short"])
+def test_short_one_operand_divisions_are_the_ieee_ones(fn):
+    """rl_recipf / rl_div200f (rl_core.h): 1 / x and x / 200 in three operations for waves whose arguments are normal floats with
+    2^-100 <= |x| < 2^100.  tools/sqrt_exhaustive.hip compares every such float of either sign on the device
+    (profiles/r04_sqrt_exhaustive.txt: 0 of 3.36 G differ); here: every positive one through the library's probe against
+    numpy's IEEE division, negative ones and mixed waves (zeros, denormals, huge, infinities, NaN: the compiler's form) sampled."""
+    ref = (lambda x: np.float32(1.0) / x) if fn == "recip_short" else (lambda x: x / np.float32(200.0))
+    lo, hi = 0x0d800000, 0x71800000
+    step = 1 << 25
+    for first in range(lo, hi, step):
+        x = np.arange(first, min(first + step, hi), dtype=np.uint32).view(np.float32)
+        assert R.math_probe(fn, x).view(np.uint32).tobytes() == ref(x).view(np.uint32).tobytes(), hex(first)
+    rng = np.random.default_rng(6)
+    neg = (rng.integers(lo, hi, 1 << 22, dtype=np.uint64).astype(np.uint32) | np.uint32(0x80000000)).view(np.float32)
+    assert R.math_probe(fn, neg).view(np.uint32).tobytes() == ref(neg).view(np.uint32).tobytes()
+    odd = rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    odd[::3] = np.array([0.0, -0.0, np.inf, -np.inf, 1e-40, 3e37], np.float32)[rng.integers(0, 6, len(odd[::3]))]
+    with np.errstate(all="ignore"):
+        want = ref(odd)
+    got = R.math_probe(fn, odd)
+    both_nan = np.isnan(got) & np.isnan(want)
+    assert np.array_equal(got.view(np.uint32)[~both_nan], want.view(np.uint32)[~both_nan])
+
+
 def test_normalise_with_the_shared_reciprocal_is_the_ieee_division_bit_for_bit():
     """rl_normalise (vector3.rs:56-67) divides three components by one length; on the device the reciprocal's refinement is
     shared and the scaling / fix-up steps of the compiler's division are skipped where they pass their operands through
