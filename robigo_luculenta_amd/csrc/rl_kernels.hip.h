@@ -151,6 +151,10 @@ __device__ __forceinline__ void rl_wave_sync() {
 __device__ __forceinline__ uint32_t rl_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
+// base + that count: the instruction pair adds onto its third operand, so a ring's tail goes in there instead of a v_add behind it
+__device__ __forceinline__ uint32_t rl_mbcnt_from(uint64_t mask, uint32_t base) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, base));
+}
 
 // Cross-lane fetches of a round: every lane reads the values of its pair's owner lane.  The bpermutes are issued back to
 // back and waited for once -- the build's register-minimising scheduler otherwise issues them one at a time, each
@@ -394,7 +398,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u) | (DISABLE_BIT)) >= 0;               \
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
         if (m != 0) {                                                                               \
-            if (cand) ring_b[(b_tail + rl_mbcnt(m)) & 127u] = ((POS) << 6) | (OWNER);               \
+            if (cand) ring_b[rl_mbcnt_from(m, b_tail) & 127u] = ((POS) << 6) | (OWNER);               \
             b_tail += (uint32_t)__popcll(m);                                                        \
             if (b_tail - b_head >= 64u) {                                                           \
                 process_spheres(64u);                                                               \
@@ -484,7 +488,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
             const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed | 0x80000000u); // (a lane with nothing left does not push; ctz(0) is undefined)
-            if (passed != 0u) ring_b[(b_tail + rl_mbcnt(any)) & 127u] = ((first + j) << 6) | owner;
+            if (passed != 0u) ring_b[rl_mbcnt_from(any, b_tail) & 127u] = ((first + j) << 6) | owner;
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;
             if (b_tail - b_head >= 64u) {
@@ -515,7 +519,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }                                                                                               \
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                           \
         if (m != 0) {                                                                                   \
-            if (pass) ring_a[(a_tail + rl_mbcnt(m)) & 127u] = ((first + (J) - (ITEM_BASE)) << 6) | owner; \
+            if (pass) ring_a[rl_mbcnt_from(m, a_tail) & 127u] = ((first + (J) - (ITEM_BASE)) << 6) | owner; \
             a_tail += (uint32_t)__popcll(m);                                                            \
             if (a_tail - a_head >= 64u) {                                                               \
                 PROCESS_A(64u);                                                                         \
@@ -564,7 +568,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
             g0 = gb[g + 1];                                                                             \
             if (m != 0) {                                                                               \
-                if (pass) ring_s[(s_tail + rl_mbcnt(m)) & 127u] = (g << 6) | lane; /* group number within its kind */ \
+                if (pass) ring_s[rl_mbcnt_from(m, s_tail) & 127u] = (g << 6) | lane; /* group number within its kind */ \
                 s_tail += (uint32_t)__popcll(m);                                                        \
                 if (s_tail - s_head >= 64u) {                                                           \
                     RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                   \
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
             if (m != 0) {
                 if (ended_on_emitter) {
-                    const uint32_t slot = (e_tail + rl_mbcnt(m)) & 127u;
+                    const uint32_t slot = rl_mbcnt_from(m, e_tail) & 127u;
                     emit[0 * 128 + slot] = p.sx;
                     emit[1 * 128 + slot] = p.sy;
                     emit[2 * 128 + slot] = p.wavelength;
