@@ -44,29 +44,6 @@ RL_HD float rl_dot(RlF3 a, RlF3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                                                // vector3.rs:27-33
     return rl_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-// The IEEE square root (f32::sqrt of the reference: geometry.rs:217,326, material.rs:244, monte_carlo.rs:53-57, vector3.rs:52).
-// The compiler's correctly rounded expansion is 16 instructions, half of them in the half-rate classes (scale the argument out
-// of the denormal range and back, the hardware's 1-ulp root, two neighbours tried by residual, a class fix-up).  On gfx950
-//     y = v_rsq_f32(x);  s = x y;  h = y / 2;  s + (x - s s) h      (two products, two fused multiply-adds)
-// IS that root for every normal x >= 2^-96 -- not argued: tools/sqrt_exhaustive.hip compares the two for all 1,879,048,192
-// such floats on the device (0 differ; the hardware root alone differs for 284 M of them), and
-// test_short_square_root_is_the_ieee_one_for_every_normal_float repeats it through the library.  Arguments outside that range
-// (zero, denormals and the smallest normals, infinity, NaN, negative numbers) make the WAVE take the compiler's form.
-// magnitude_only: the caller discards the root of a negative argument (the paraboloid's discriminant), so |x| is rooted instead
-// and negative arguments do not cost the wave its short form.
-RL_HD float rl_sqrtf(float x, bool magnitude_only = false) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float a = magnitude_only ? fabsf(x) : x;
-    const bool in_range = rl_f2u(a) - 0x0f800000u < 0x7f800000u - 0x0f800000u; // 2^-96 <= a < infinity
-    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
-        const float y = __builtin_amdgcn_rsqf(a);
-        const float s = a * y, h = 0.5f * y;
-        return __builtin_fmaf(__builtin_fmaf(-s, s, a), h, s);
-    }
-#endif
-    return sqrtf(x);
-}
-
 // Two one-operand IEEE divisions in three operations each, where the wave's arguments are normal floats with 2^-100 <= |x| < 2^100
 // (else the compiler's 11-instruction division): 1 / x = y + (1 - x y) y with y = v_rcp_f32(x) (material.rs:224), and
 // x / 200 = q + (x - 200 q) c with c = fl(1 / 200), q = x c (material.rs:283, camera.rs:100).  Like rl_sqrtf's short form these ARE
