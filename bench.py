@@ -317,6 +317,13 @@ def executed_live(args, committed, timeout_s=100.0):
     return live
 
 
+def staged_where(ran):
+    """What the launches behind `ran` (a difference of rl_debug_variant_launches) kept in LDS, as the workload text says it."""
+    if sum(ran[16:24]):
+        return "tables (planes, prisms, cull table) in LDS, spheres and objects from L2 / HBM"
+    return "primitives in LDS" if sum(ran[8:16]) else "primitives in global/scalar cache"
+
+
 def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches, seed, device):
     """Times `launches` fused launches of one config; returns the per-launch figures."""
     objs, cam, W, H, label = scene_of(R, config)
@@ -326,6 +333,7 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
     plot = R.PlotUnit(rank, W, H, device=device)
     n = batches_per_launch * BATCH
     nxt = 0
+    variants0 = R.variant_launches()
     for _ in range(warm_launches):
         trace.render_fused(scene, plot, n, seed=seed, stream=rank, first_path_index=nxt)
         nxt += n
@@ -346,8 +354,8 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
     if not executed.get("stale"):   # the short form: what SURVEY 8(d) asks for per config (VALUUtilization = active lanes)
         executed = {k: executed[k] for k in ("profile", "build_id", "valu_insts_per_64ray_segment", "cycles_per_valu_inst_per_simd",
                                               "issue_frac_vs_2cyc", "active_lanes", "useful_lane_slots_vs_2cyc")}
-    return {"config": config, "executed": executed, "workload": "built-in %s scene (%d objects), %dx%d, primitives in %s, %d launches of %d batches"
-            % (label, len(objs), W, H, "LDS" if fetch == "lds" else "global/scalar cache", launches, batches_per_launch),
+    return {"config": config, "executed": executed, "workload": "built-in %s scene (%d objects), %dx%d, %s, %d launches of %d batches"
+            % (label, len(objs), W, H, staged_where([a - b for a, b in zip(R.variant_launches(), variants0)]), launches, batches_per_launch),
             "value": (s1 - s0) / (t1 - t0) / 1e6, "unit": "Mrays/s", "mpaths_per_s": (p1 - p0) / (t1 - t0) / 1e6,
             "kernel_ms_per_launch": launch_ms, "algorithmic_flops_per_ray": f_seg,
             "roofline_algorithmic": {"achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
@@ -533,6 +541,7 @@ def main():
     scene = R.Scene(objs, cam, device=device)
     trace = R.TraceUnit(rank, W, H, n_photons=64, device=device)  # fused mode does not use mapped_photons
     trace.set_fetch(R.FETCH_LDS if args.fetch == "lds" else R.FETCH_GLOBAL)
+    variants0 = R.variant_launches()
     plot = R.PlotUnit(rank, W, H, device=device)
     gather = R.GatherUnit(W, H, device=device) if rank == 0 else None
     next_path = [0]
@@ -665,12 +674,12 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "built-in %s scene (%d objects), %dx%d, fused trace+plot; one step = %d launches of %d batches of "
-                                   "524288 paths per GPU, then the gather (%s); RNG stream = rank, primitives in %s"
+                                   "524288 paths per GPU, then the gather (%s); RNG stream = rank, %s"
                                    % (label, len(objs), W, H, args.launches_per_step, args.batches_per_launch,
                                       "Kahan accumulate + clear" if world == 1 else
                                       ("RCCL reduce of the XYZ buffers onto rank 0, Kahan accumulate, clear" if comm is not None
                                        else "host-staged gloo sum onto rank 0, Kahan accumulate, clear"),
-                                      "LDS" if args.fetch == "lds" else "global/scalar cache"),
+                                      staged_where([a - b for a, b in zip(R.variant_launches(), variants0)])),
                        "config": args.config, "paths_per_step_per_gpu": paths_per_launch * args.launches_per_step,
                        "paths_per_launch": paths_per_launch, "seed": args.seed, "build_id": R.build_id(),
                        "total_paths_per_step": paths_per_launch * args.launches_per_step * world,

@@ -93,6 +93,9 @@ enum RlBuiltinScene {
 };
 
 /* Where the trace kernel reads the primitive list from. */
+// RL_FETCH_LDS stages as much as fits beside the waves' scratch: the whole scene (up to about 1,300 objects), else its tables
+// (planes, paraboloids, prisms, the cull table) with the spheres and objects read from L2 / HBM, else -- tables beyond ~37 KB,
+// tens of thousands of objects -- nothing.  RL_FETCH_GLOBAL never stages anything.
 enum RlPrimitiveFetch {
     RL_FETCH_LDS = 0,   /* primitives + CIE tables staged in LDS by each workgroup */
     RL_FETCH_GLOBAL = 1 /* wave-uniform loads from HBM/L2 through the scalar cache */

@@ -18,9 +18,10 @@ int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n
 /* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
  * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
 int rl_debug_batch_histogram(int device, uint64_t* out);
-/* out[v], v = 0..15: launches of instantiation v of the trace kernel since the library was loaded, v = 8 * (primitives
- * staged in LDS) + 4 * (trace fused with the splat) + 2 * (open launch: a blocking render call) + 1 * (prisms carry a second
- * bound).  The parity matrix (tests/test_gpu_parity.py) asserts with it that the variant it means to test is the one that ran. */
+/* out[v], v = 0..23: launches of instantiation v of the trace kernel since the library was loaded.  v < 16: v = 8 * (the whole
+ * scene staged in LDS) + 4 * (trace fused with the splat) + 2 * (open launch: a blocking render call) + 1 * (prisms carry a
+ * second bound); v = 16 + the low three bits: the variants that stage the scene's tables only (a scene too large for LDS).
+ * The parity matrix (tests/test_gpu_parity.py) asserts with it that the variant it means to test is the one that ran. */
 int rl_debug_variant_launches(uint64_t* out);
 /* The prism shortcut (csrc/rl_core.h: rl_hex_prism_fast) against the Compound tree it stands in for
  * (geometry.rs:380-407), both evaluated ON THE GPU -- with the hardware's v_rcp_f32 -- for n rays against prism

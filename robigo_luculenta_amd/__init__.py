@@ -400,8 +400,9 @@ def batch_histogram(device=0):
 
 def variant_launches():
     """rl_debug_variant_launches: launches per instantiation of the trace kernel since the library was loaded;
-    index = 8 * staged in LDS + 4 * fused + 2 * open launch + 1 * prisms with a second bound."""
-    out = (C.c_uint64 * 16)()
+    index = 8 * whole scene staged in LDS + 4 * fused + 2 * open launch + 1 * prisms with a second bound; 16 + the low three
+    bits for the variants that stage the scene's tables only."""
+    out = (C.c_uint64 * 24)()
     check(lib.rl_debug_variant_launches(out))
     return list(out)
 

@@ -83,7 +83,8 @@ struct RlScene {
     int device;
     RlF4* blob;
     RlSceneLayout lay;
-    size_t staged_bytes;
+    size_t staged_bytes; // the whole blob
+    size_t tables_bytes; // its tables: records [off_planes, off_objects)
 };
 
 namespace {
@@ -189,20 +190,43 @@ int drain_events(RlTraceUnit* u) {
 // the splat or not, an open launch or a plain one, prisms with a second bound or without.
 typedef void (*TraceKernel)(const RlF4*, RlSceneLayout, RlTraceJob, RlMappedPhoton*, float*, unsigned long long*, const RlJobEntry*,
                             RlOpenDev*, RlOpenCtl*);
-std::atomic<uint64_t> g_variant_launches[16]; // rl_debug_variant_launches: launches per instantiation since the library was loaded
-TraceKernel trace_kernel_variant(bool stage, bool fused, bool open, bool cyl) {
-    g_variant_launches[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)].fetch_add(1, std::memory_order_relaxed);
-    static const TraceKernel table[16] = {
-        rl_trace_kernel<false, false, false, false>, rl_trace_kernel<false, false, false, true>,
-        rl_trace_kernel<false, false, true, false>,  rl_trace_kernel<false, false, true, true>,
-        rl_trace_kernel<false, true, false, false>,  rl_trace_kernel<false, true, false, true>,
-        rl_trace_kernel<false, true, true, false>,   rl_trace_kernel<false, true, true, true>,
-        rl_trace_kernel<true, false, false, false>,  rl_trace_kernel<true, false, false, true>,
-        rl_trace_kernel<true, false, true, false>,   rl_trace_kernel<true, false, true, true>,
-        rl_trace_kernel<true, true, false, false>,   rl_trace_kernel<true, true, false, true>,
-        rl_trace_kernel<true, true, true, false>,    rl_trace_kernel<true, true, true, true>,
+std::atomic<uint64_t> g_variant_launches[24]; // rl_debug_variant_launches: launches per instantiation since the library was loaded
+// stage: RL_STAGE_NONE / RL_STAGE_TABLES / RL_STAGE_ALL.  Index = the four template arguments as bits -- 8: the whole scene in LDS,
+// 4: fused, 2: open, 1: cylinders -- and 16 + the low three for the variants that stage the tables only.
+TraceKernel trace_kernel_variant(int stage, bool fused, bool open, bool cyl) {
+    const int low = (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0);
+    const int index = stage == RL_STAGE_TABLES ? 16 + low : (stage == RL_STAGE_ALL ? 8 : 0) | low;
+    g_variant_launches[index].fetch_add(1, std::memory_order_relaxed);
+    static const TraceKernel table[24] = {
+        rl_trace_kernel<RL_STAGE_NONE, false, false, false>, rl_trace_kernel<RL_STAGE_NONE, false, false, true>,
+        rl_trace_kernel<RL_STAGE_NONE, false, true, false>,  rl_trace_kernel<RL_STAGE_NONE, false, true, true>,
+        rl_trace_kernel<RL_STAGE_NONE, true, false, false>,  rl_trace_kernel<RL_STAGE_NONE, true, false, true>,
+        rl_trace_kernel<RL_STAGE_NONE, true, true, false>,   rl_trace_kernel<RL_STAGE_NONE, true, true, true>,
+        rl_trace_kernel<RL_STAGE_ALL, false, false, false>,  rl_trace_kernel<RL_STAGE_ALL, false, false, true>,
+        rl_trace_kernel<RL_STAGE_ALL, false, true, false>,   rl_trace_kernel<RL_STAGE_ALL, false, true, true>,
+        rl_trace_kernel<RL_STAGE_ALL, true, false, false>,   rl_trace_kernel<RL_STAGE_ALL, true, false, true>,
+        rl_trace_kernel<RL_STAGE_ALL, true, true, false>,    rl_trace_kernel<RL_STAGE_ALL, true, true, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, false, false, false>, rl_trace_kernel<RL_STAGE_TABLES, false, false, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, false, true, false>,  rl_trace_kernel<RL_STAGE_TABLES, false, true, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, true, false, false>,  rl_trace_kernel<RL_STAGE_TABLES, true, false, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, true, true, false>,   rl_trace_kernel<RL_STAGE_TABLES, true, true, true>,
     };
-    return table[(stage ? 8 : 0) | (fused ? 4 : 0) | (open ? 2 : 0) | (cyl ? 1 : 0)];
+    return table[index];
+}
+// What a launch stages in LDS beside `scratch_bytes` of per-wave scratch: the whole scene where it fits, its tables where
+// those do, nothing otherwise (or when the unit was created with RL_FETCH_GLOBAL); *bytes = the staged size.
+int stage_of(const RlScene* scene, int fetch, size_t scratch_bytes, size_t* bytes) {
+    *bytes = 0;
+    if (fetch != RL_FETCH_LDS) return RL_STAGE_NONE;
+    if (scene->staged_bytes + scratch_bytes <= 160 * 1024) {
+        *bytes = scene->staged_bytes;
+        return RL_STAGE_ALL;
+    }
+    if (scene->tables_bytes + scratch_bytes <= 160 * 1024) {
+        *bytes = scene->tables_bytes;
+        return RL_STAGE_TABLES;
+    }
+    return RL_STAGE_NONE;
 }
 
 // One launch of the trace kernel on u's stream: n_paths paths from first_path on, into `photons` (un-fused) or splatted
@@ -229,12 +253,12 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
 
     // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
-    const size_t blob_bytes = scene->staged_bytes;
-    const bool stage = (u->fetch == RL_FETCH_LDS) && blob_bytes + scratch_bytes <= 160 * 1024;
+    size_t blob_bytes = 0;
+    const int stage = stage_of(scene, u->fetch, scratch_bytes, &blob_bytes);
     const bool fused = plot != nullptr;
     const bool cyl = scene->lay.prism_cylinders != 0u;
     auto kernel = trace_kernel_variant(stage, fused, false, cyl);
-    const size_t dyn = scratch_bytes + (stage ? blob_bytes : 0);
+    const size_t dyn = scratch_bytes + blob_bytes;
     if (u->tuned_per_cu == 0 || u->tuned_dyn != dyn || u->tuned_kernel != (const void*)kernel) { // once per (unit, scene size, variant)
         // The limit is a property of the function, shared by every unit: always raise it to the whole LDS.
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -392,7 +416,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     if (rc != RL_OK) return fail(rc, err);
     if ((rc = use_device(device)) != RL_OK) return rc;
 
-    // One blob: spheres | planes | parabs | prisms | objects | cie | sphere_obj (padded to 16 B).
+    // One blob: spheres || planes | parabs | prisms | cull table | prism cylinders | camera || objects | cie | sphere_obj | sphere_r2 (padded to 16 B).
     std::vector<RlF4> blob;
     RlSceneLayout lay;
     std::memset(&lay, 0, sizeof lay);
@@ -403,16 +427,18 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     };
     append(fs.spheres);
     for (size_t pos = fs.cluster_base; pos < fs.spheres.size(); ++pos) blob[pos].w = fs.sphere_cull_w[pos]; // see RlSceneView::sphere_r2
+    // the tables (RlSceneLayout: records [off_planes, off_objects)) ...
     lay.off_planes = append(fs.planes);
     lay.off_parabs = append(fs.parabs);
     lay.off_prisms = append(fs.prisms);
-    lay.off_objects = append(fs.objects);
     lay.off_cull = append(fs.cull_bounds);
     lay.off_prism_cyl = append(fs.prism_cyl);
     lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
     lay.group_gc = fs.group_gc;
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
+    // ... then the per-object arrays
+    lay.off_objects = append(fs.objects);
     lay.off_cie = (uint32_t)blob.size();
     const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
     blob.insert(blob.end(), cie, cie + RL_CIE_SAMPLES);
@@ -441,6 +467,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     s->device = device;
     s->lay = lay;
     s->staged_bytes = blob.size() * sizeof(RlF4);
+    s->tables_bytes = (size_t)(lay.off_objects - lay.off_planes) * sizeof(RlF4);
     s->blob = nullptr;
     hipError_t e = hipMalloc((void**)&s->blob, s->staged_bytes);
     if (e == hipSuccess) e = hipMemcpy(s->blob, blob.data(), s->staged_bytes, hipMemcpyHostToDevice);
@@ -692,9 +719,10 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     job.wm1 = (float)(int)u->width - 1.0f;
     job.hm1 = (float)(int)u->height - 1.0f;
     const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
-    const bool stage = (u->fetch == RL_FETCH_LDS) && scene->staged_bytes + scratch_bytes <= 160 * 1024;
+    size_t blob_bytes = 0;
+    const int stage = stage_of(scene, u->fetch, scratch_bytes, &blob_bytes);
     auto kernel = trace_kernel_variant(stage, fused, true, scene->lay.prism_cylinders != 0u);
-    const size_t dyn = scratch_bytes + (stage ? scene->staged_bytes : 0);
+    const size_t dyn = scratch_bytes + blob_bytes;
     if (x.tuned_kernel != (const void*)kernel || x.tuned_dyn != dyn) { // once per (slot, variant, scene size)
         RL_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         int n = 1;
@@ -1654,7 +1682,7 @@ int rl_debug_batch_histogram(int device, uint64_t* out) {
 // in LDS) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound).
 int rl_debug_variant_launches(uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
-    for (int k = 0; k < 16; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
+    for (int k = 0; k < 24; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
     return RL_OK;
 }
 

@@ -41,7 +41,12 @@ struct RlSceneLayout {
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
     uint32_t group_gc;                         // RlFlatScene::group_gc: clusters per group of the cull table
+    // Records [off_planes, off_objects) of the blob are the TABLES -- planes, paraboloids, prisms, the cull table, the camera:
+    // everything a scan reads with wave-uniform addresses or once per (group, ray) / (prism, ray) pair, 10-40 KB whatever the
+    // scene's size.  The spheres in front of them and the per-object arrays behind them grow with the scene: one too large for
+    // LDS stages its tables only (RL_STAGE_TABLES).
 };
+enum { RL_STAGE_NONE = 0, RL_STAGE_TABLES = 1, RL_STAGE_ALL = 2 };
 
 struct RlTraceJob {
     uint32_t width, height;
@@ -665,7 +670,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 
 // queue[0] = next unassigned path offset of this launch (zeroed before each launch),
 // queue[1] = cumulative segments, queue[2] = cumulative paths.
-// Dynamic LDS: [scene blob when STAGE_LDS][RlWaveScratch x 16].
+// Dynamic LDS: [scene blob (RL_STAGE_ALL) or its tables (RL_STAGE_TABLES)][RlWaveScratch x 16].
 // FUSED: paths that end on a light are splatted into `plot` (photons unused); otherwise every path's
 // MappedPhoton goes to `photons` (plot unused).  A compile-time switch so neither variant carries the
 // other's code and registers.
@@ -674,7 +679,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // plain launch -- every bulk launch -- carries none of the bookkeeping (measured 1 % on the fused kernel).
 // CYL: the scene's prisms carry a second bound (RlFlatScene::prism_cylinders) -- a compile-time switch so that scenes
 // without it run exactly the code they ran before it existed.
-template <bool STAGE_LDS, bool FUSED, bool OPEN, bool CYL>
+template <int STAGE, bool FUSED, bool OPEN, bool CYL>
 // At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
 // the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
 __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
@@ -683,24 +688,31 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                                                                   unsigned long long* __restrict__ queue,
                                                                   const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
-    const RlF4* base = scene;
+    const RlF4* base = scene; // the tables
+    const RlF4* big = scene;  // the per-sphere and per-object arrays
     RlWaveScratch* scratch = (RlWaveScratch*)smem;
-    if (STAGE_LDS) {
+    if (STAGE == RL_STAGE_ALL) {
         for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_TRACE_BLOCK) smem[i] = scene[i];
         __syncthreads();
-        base = smem;
+        base = big = smem;
         scratch = (RlWaveScratch*)(smem + lay.total_f4);
+    } else if (STAGE == RL_STAGE_TABLES) {
+        const uint32_t n_staged = lay.off_objects - lay.off_planes;
+        for (uint32_t i = threadIdx.x; i < n_staged; i += RL_TRACE_BLOCK) smem[i] = scene[lay.off_planes + i];
+        __syncthreads();
+        base = smem - lay.off_planes; // (only ever used with a table's offset added)
+        scratch = (RlWaveScratch*)(smem + n_staged);
     }
 
     RlSceneView sv;
-    sv.spheres = base;
+    sv.spheres = big;
     sv.planes = base + lay.off_planes;
     sv.parabs = base + lay.off_parabs;
     sv.prisms = base + lay.off_prisms;
-    sv.objects = base + lay.off_objects;
-    sv.cie = base + lay.off_cie;
-    sv.sphere_obj = (const uint32_t*)(base + lay.off_sphere_obj);
-    sv.sphere_r2 = (const float*)(base + lay.off_sphere_r2);
+    sv.objects = big + lay.off_objects;
+    sv.cie = big + lay.off_cie;
+    sv.sphere_obj = (const uint32_t*)(big + lay.off_sphere_obj);
+    sv.sphere_r2 = (const float*)(big + lay.off_sphere_r2);
     sv.n_direct = lay.n_direct;
     sv.n_direct_padded = lay.n_direct_padded;
     sv.cluster_base = lay.cluster_base;
@@ -1066,7 +1078,9 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_s_sleep(127); // ~15 us: thousands of waves poll the same few words
             continue;
         }
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE_LDS>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        // (ring-S rounds unrolled wherever the cull table is in LDS -- except in the fused open launches of a tables-only scene, the
+        // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
+        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE == RL_STAGE_ALL || (STAGE == RL_STAGE_TABLES && !(FUSED && OPEN))>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {

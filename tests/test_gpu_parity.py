@@ -435,8 +435,8 @@ def test_app_worker_pool_renders_the_same_image_as_the_oracle(demo, fused, concu
 
 def test_scene_too_large_for_lds_spills_to_global_fetch():
     """BASELINE config 5's "LDS-spill / global-HBM primitive path": with 1500 seeds per spiral the scene
-    blob plus the per-wave scratch exceed 160 KB of LDS, so RL_FETCH_LDS silently reads the primitives
-    from HBM/L2 instead -- results must not change."""
+    blob plus the per-wave scratch exceed 160 KB of LDS, so RL_FETCH_LDS stages the scene's tables (planes, prisms,
+    the cull table) and reads the spheres and objects from HBM/L2 instead -- results must not change."""
     objs, cam = R.builtin_scene_desc(R.SCENE_DEMO, 1500)
     assert len(objs) > 4500
     scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
@@ -447,7 +447,56 @@ def test_scene_too_large_for_lds_spills_to_global_fetch():
     want, segs = oscene.render(W, H, 2, 0, 0, N, threads=8)
     assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
     ran = [a - b for a, b in zip(R.variant_launches(), before)]
-    assert sum(ran[:8]) >= 1 and sum(ran[8:]) == 0, ran         # a global-fetch instantiation, although the unit asked for LDS
+    assert sum(ran[16:]) >= 1 and sum(ran[:16]) == 0, ran       # an instantiation that stages the tables only, although the unit asked for LDS
+
+
+_TABLES_SCENES = {}
+
+
+@pytest.mark.parametrize("scene_name", ["seeds", "prisms"])         # 4,539 objects, 22 prisms; 3,000 random spheres, 48 prisms with a second bound (CYL)
+@pytest.mark.parametrize("open_launch", [False, True], ids=["plain", "open"])
+@pytest.mark.parametrize("fused", [False, True], ids=["unfused", "fused"])
+def test_parity_matrix_over_the_eight_instantiations_that_stage_the_tables(fused, open_launch, scene_name):
+    """The parity matrix above for rl_trace_kernel<RL_STAGE_TABLES, fused, open, cyl>: scenes too large for LDS whose planes,
+    prisms and cull table are staged and whose spheres and objects come from global memory."""
+    if scene_name not in _TABLES_SCENES:
+        if scene_name == "seeds":
+            objs, cam = R.builtin_scene_desc(R.SCENE_DEMO, 1500)
+        else:
+            import _random_scene as RS
+            objs, cam = RS.random_scene(77, n_spheres=3000, n_prisms=48, n_planes=2, n_circles=3, n_parabs=1)
+        _TABLES_SCENES[scene_name] = (R.Scene(objs, cam), O.Scene(objs, _ocam(cam)), {})
+    scene, oscene, cache = _TABLES_SCENES[scene_name]
+    W, H, N = 320, 180, 1 << 13
+    seed, stream, first = 6, 3, 4096
+    if "want" not in cache:
+        cache["want"] = oscene.render(W, H, seed, stream, first, N, threads=8)
+    want, segs = cache["want"]
+    t = R.TraceUnit(0, W, H, n_photons=N)
+    before = R.variant_launches()
+    if not fused:
+        if open_launch:
+            t.render(scene, seed=seed, stream=stream, first_path_index=first)
+        else:
+            t.render_async(scene, seed=seed, stream=stream, first_path_index=first)
+            t.sync()
+        assert t.mapped_photons.tobytes() == want.tobytes()
+    else:
+        p = R.PlotUnit(0, W, H)
+        if open_launch:
+            t.render_fused_sync(scene, p, N, seed=seed, stream=stream, first_path_index=first)
+        else:
+            t.render_fused(scene, p, N, seed=seed, stream=stream, first_path_index=first)
+            t.sync()
+        got = p.tristimulus_buffer
+        ref = O.plot(W, H, want)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-6 * np.abs(ref).max())
+        assert got.any()
+    paths, segments, _ = t.stats()
+    assert (paths, segments) == (N, segs)
+    ran = [a - b for a, b in zip(R.variant_launches(), before)]
+    meant = 16 | (4 if fused else 0) | (2 if open_launch else 0) | (1 if scene_name == "prisms" else 0)
+    assert ran[meant] >= 1 and sum(ran) == ran[meant], (meant, ran)
 
 
 @pytest.mark.parametrize("seed", [31, 32, 33, 34])

@@ -52,4 +52,4 @@ for k in range(scenes):
             bad += 1
             print("MISMATCH scene", k, "spheres", n_spheres, "prisms", n_prisms, "fetch", fetch)
 print("%d random scenes (%d..%d objects), %d photons each, %s: %d rays checked, %d mismatching renders, %.1f s"
-      % (scenes, min(sizes), max(sizes), N, "spilled to global fetch" if BIG else "both fetch modes", (1 if BIG else 2) * rays, bad, time.time() - t0))
+      % (scenes, min(sizes), max(sizes), N, "too large for LDS (tables staged, spheres and objects from L2 / HBM)" if BIG else "both fetch modes", (1 if BIG else 2) * rays, bad, time.time() - t0))
