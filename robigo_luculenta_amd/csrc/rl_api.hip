@@ -1678,8 +1678,9 @@ int rl_debug_batch_histogram(int device, uint64_t* out) {
     return RL_OK;
 }
 
-// Diagnostics: launches of each instantiation of the trace kernel since the library was loaded; index = 8 * (primitives staged
-// in LDS) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound).
+// Diagnostics: launches of each of the 24 instantiations of the trace kernel since the library was loaded; index = 8 * (the whole
+// scene staged in LDS) + 4 * (fused with the splat) + 2 * (open launch) + 1 * (prisms with a second bound), and 16 + the low three
+// bits for the instantiations that stage the tables only (trace_kernel_variant).
 int rl_debug_variant_launches(uint64_t* out) {
     if (!out) return fail(RL_E_INVALID, "null argument");
     for (int k = 0; k < 24; ++k) out[k] = g_variant_launches[k].load(std::memory_order_relaxed);
