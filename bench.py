@@ -230,6 +230,8 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
     traffic = None
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # MI355X_MICROARCH.md: FETCH_SIZE halves wide reads on gfx950
+        if paths_per_launch and d.get("paths_per_launch"):  # per launch of THIS run: the splat's bytes are proportional to the paths
+            traffic *= paths_per_launch / d["paths_per_launch"]
     return out, traffic
 
 
@@ -712,7 +714,7 @@ def main():
                          "traffic": traffic,
                          "hbm": ({"achieved": traffic / (launch_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                   "frac": traffic / (launch_ms * 1e-3) / 8e12} if traffic else None),
-                         "traffic_note": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB of the profile named in `executed` "
+                         "traffic_note": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB of the profile named in `executed`, scaled to this run's paths per launch "
                                          "(each f32 atomic is billed as one 32-byte write); algorithmic: 48 B per contributing path; "
                                          "null when the profile is stale",
                          "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only"},
