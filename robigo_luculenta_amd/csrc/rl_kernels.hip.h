@@ -700,15 +700,16 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         const uint32_t n_staged = lay.off_objects - lay.off_planes;
         for (uint32_t i = threadIdx.x; i < n_staged; i += RL_TRACE_BLOCK) smem[i] = scene[lay.off_planes + i];
         __syncthreads();
-        base = smem - lay.off_planes; // (only ever used with a table's offset added)
+        base = smem;
         scratch = (RlWaveScratch*)(smem + n_staged);
     }
+    const uint32_t tab0 = STAGE == RL_STAGE_TABLES ? lay.off_planes : 0u; // blob offset of `base`'s first record
 
     RlSceneView sv;
     sv.spheres = big;
-    sv.planes = base + lay.off_planes;
-    sv.parabs = base + lay.off_parabs;
-    sv.prisms = base + lay.off_prisms;
+    sv.planes = base + (lay.off_planes - tab0);
+    sv.parabs = base + (lay.off_parabs - tab0);
+    sv.prisms = base + (lay.off_prisms - tab0);
     sv.objects = big + lay.off_objects;
     sv.cie = big + lay.off_cie;
     sv.sphere_obj = (const uint32_t*)(big + lay.off_sphere_obj);
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
     sv.n_parabs = lay.n_parabs;
     sv.n_prisms = lay.n_prisms;
     sv.n_objects = lay.n_objects;
-    sv.camera_rec = base + lay.off_camera;
+    sv.camera_rec = base + (lay.off_camera - tab0);
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
     typedef __attribute__((address_space(3))) float RlLdsF32;
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         }
         // (ring-S rounds unrolled wherever the cull table is in LDS -- except in the fused open launches of a tables-only scene, the
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE == RL_STAGE_ALL || (STAGE == RL_STAGE_TABLES && !(FUSED && OPEN))>(sv, base + lay.off_cull, CYL ? base + lay.off_prism_cyl : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE == RL_STAGE_ALL || (STAGE == RL_STAGE_TABLES && !(FUSED && OPEN))>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
