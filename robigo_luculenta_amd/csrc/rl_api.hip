@@ -198,18 +198,12 @@ TraceKernel trace_kernel_variant(int stage, bool fused, bool open, bool cyl) {
     const int index = stage == RL_STAGE_TABLES ? 16 + low : (stage == RL_STAGE_ALL ? 8 : 0) | low;
     g_variant_launches[index].fetch_add(1, std::memory_order_relaxed);
     static const TraceKernel table[24] = {
-        rl_trace_kernel<RL_STAGE_NONE, false, false, false>, rl_trace_kernel<RL_STAGE_NONE, false, false, true>,
-        rl_trace_kernel<RL_STAGE_NONE, false, true, false>,  rl_trace_kernel<RL_STAGE_NONE, false, true, true>,
-        rl_trace_kernel<RL_STAGE_NONE, true, false, false>,  rl_trace_kernel<RL_STAGE_NONE, true, false, true>,
-        rl_trace_kernel<RL_STAGE_NONE, true, true, false>,   rl_trace_kernel<RL_STAGE_NONE, true, true, true>,
-        rl_trace_kernel<RL_STAGE_ALL, false, false, false>,  rl_trace_kernel<RL_STAGE_ALL, false, false, true>,
-        rl_trace_kernel<RL_STAGE_ALL, false, true, false>,   rl_trace_kernel<RL_STAGE_ALL, false, true, true>,
-        rl_trace_kernel<RL_STAGE_ALL, true, false, false>,   rl_trace_kernel<RL_STAGE_ALL, true, false, true>,
-        rl_trace_kernel<RL_STAGE_ALL, true, true, false>,    rl_trace_kernel<RL_STAGE_ALL, true, true, true>,
-        rl_trace_kernel<RL_STAGE_TABLES, false, false, false>, rl_trace_kernel<RL_STAGE_TABLES, false, false, true>,
-        rl_trace_kernel<RL_STAGE_TABLES, false, true, false>,  rl_trace_kernel<RL_STAGE_TABLES, false, true, true>,
-        rl_trace_kernel<RL_STAGE_TABLES, true, false, false>,  rl_trace_kernel<RL_STAGE_TABLES, true, false, true>,
-        rl_trace_kernel<RL_STAGE_TABLES, true, true, false>,   rl_trace_kernel<RL_STAGE_TABLES, true, true, true>,
+        rl_trace_kernel<RL_STAGE_NONE, false, false>, rl_trace_kernel<RL_STAGE_NONE, false, true>, rl_trace_kernel_open<RL_STAGE_NONE, false, false>, rl_trace_kernel_open<RL_STAGE_NONE, false, true>,
+        rl_trace_kernel<RL_STAGE_NONE, true, false>, rl_trace_kernel<RL_STAGE_NONE, true, true>, rl_trace_kernel_open<RL_STAGE_NONE, true, false>, rl_trace_kernel_open<RL_STAGE_NONE, true, true>,
+        rl_trace_kernel<RL_STAGE_ALL, false, false>, rl_trace_kernel<RL_STAGE_ALL, false, true>, rl_trace_kernel_open<RL_STAGE_ALL, false, false>, rl_trace_kernel_open<RL_STAGE_ALL, false, true>,
+        rl_trace_kernel<RL_STAGE_ALL, true, false>, rl_trace_kernel<RL_STAGE_ALL, true, true>, rl_trace_kernel_open<RL_STAGE_ALL, true, false>, rl_trace_kernel_open<RL_STAGE_ALL, true, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, false, false>, rl_trace_kernel<RL_STAGE_TABLES, false, true>, rl_trace_kernel_open<RL_STAGE_TABLES, false, false>, rl_trace_kernel_open<RL_STAGE_TABLES, false, true>,
+        rl_trace_kernel<RL_STAGE_TABLES, true, false>, rl_trace_kernel<RL_STAGE_TABLES, true, true>, rl_trace_kernel_open<RL_STAGE_TABLES, true, false>, rl_trace_kernel_open<RL_STAGE_TABLES, true, true>,
     };
     return table[index];
 }
@@ -265,6 +259,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         int per_cu = 1;
         RL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RL_TRACE_BLOCK, dyn));
         u->tuned_per_cu = per_cu < 1 ? 1 : per_cu;
+        if (getenv("RL_DEBUG_LAUNCH")) fprintf(stderr, "rl: trace launch: %d workgroup(s) of %d threads per CU, %zu bytes of LDS each, stage %d\n", per_cu, RL_TRACE_BLOCK, dyn, stage);
         u->tuned_dyn = dyn;
         u->tuned_kernel = (const void*)kernel; // (the instantiation itself, not some of its template arguments -- `cyl` was not among them)
     }
@@ -435,6 +430,15 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_prism_cyl = append(fs.prism_cyl);
     lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
     lay.group_gc = fs.group_gc;
+    {   // both lists are in object order (rl_flatten_scene appends them object by object); ordered against each other?
+        uint32_t last_parab = 0, first_plane = 0xffffffffu;
+        for (size_t i = 0; i < fs.parabs.size(); i += 3) last_parab = std::max(last_parab, rl_f2u(fs.parabs[i].w));
+        for (size_t i = 1; i < fs.planes.size(); i += 2) first_plane = std::min(first_plane, rl_f2u(fs.planes[i].w));
+        bool sorted = fs.parabs.empty() || fs.planes.empty() || last_parab < first_plane;
+        for (size_t i = 3; i < fs.parabs.size(); i += 3) sorted = sorted && rl_f2u(fs.parabs[i - 3].w) < rl_f2u(fs.parabs[i].w);
+        for (size_t i = 3; i < fs.planes.size(); i += 2) sorted = sorted && rl_f2u(fs.planes[i - 2].w) < rl_f2u(fs.planes[i].w);
+        lay.small_ordered = sorted ? 1u : 0u;
+    }
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     // ... then the per-object arrays

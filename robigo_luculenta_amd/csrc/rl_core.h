@@ -52,7 +52,7 @@ RL_HD RlF3 rl_cross(RlF3 a, RlF3 b) {                                           
 RL_HD float rl_recipf(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool in_range = (rl_f2u(x) & 0x7fffffffu) - 0x0d800000u < 0x71800000u - 0x0d800000u;
-    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!in_range) == 0)) {
         const float y = __builtin_amdgcn_rcpf(x);
         return __builtin_fmaf(__builtin_fmaf(-x, y, 1.0f), y, y);
     }
@@ -62,7 +62,7 @@ RL_HD float rl_recipf(float x) {
 RL_HD float rl_div200f(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool in_range = (rl_f2u(x) & 0x7fffffffu) - 0x0d800000u < 0x71800000u - 0x0d800000u;
-    if (__builtin_amdgcn_ballot_w64(!in_range) == 0) {
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!in_range) == 0)) {
         const float c = 0.005f, q = x * c;
         return __builtin_fmaf(__builtin_fmaf(-200.0f, q, x), c, q);
     }
@@ -88,7 +88,7 @@ RL_HD RlF3 rl_normalise(RlF3 v) {                                               
     least = bz - 1u < least ? bz - 1u : least;
     const bool plain = least >= 0x1f800000u - 1u                         // every component is 0 or at least 2^-64
                        && rl_f2u(d2) - 0x0f800000u < 0x7a800000u - 0x0f800000u; // 2^-96 <= |v|^2 < 2^118: 2^-48 <= m < 2^59 (NaN and 0 fail)
-    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) {
         const float ys = __builtin_amdgcn_rsqf(d2);
         const float s = d2 * ys, h = 0.5f * ys;
         const float m = __builtin_fmaf(__builtin_fmaf(-s, s, d2), h, s); // = sqrtf(d2), see rl_sqrtf
@@ -188,7 +188,7 @@ RL_HD float rl_sf10_ior(float wavelength) {
         r = __builtin_fma(0.5 * r, __builtin_fma(-(sum * r), r, 1.0), r);
         const double n = sum * r;
         const float lo = (float)(n * (1.0 - 9.094947017729282e-13)), hi = (float)(n * (1.0 + 9.094947017729282e-13)); // 2^-40
-        if (__builtin_amdgcn_ballot_w64(!(lo == hi)) == 0) return lo;
+        if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!(lo == hi)) == 0)) return lo;
     }
 #endif
     return (float)sqrt(1.0 + 1.737596950 * w2 / (w2 - 0.0131887070) + 0.313747346 * w2 / (w2 - 0.0623068142) +
@@ -305,7 +305,7 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     const float np = -b + sq, nq = -b - sq;
     const float pick = np < 0.0f ? np : nq;
     const bool plain = a < 0.0f && (disc < 0.0f || ((fabsf(np) >= 1.0e-37f || np == 0.0f) && (fabsf(nq) >= 1.0e-37f || nq == 0.0f)));
-    if (__builtin_amdgcn_ballot_w64(!plain) == 0) return (disc < 0.0f || !(pick < 0.0f)) ? -1.0f : 0.5f * pick / a;
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) return (disc < 0.0f || !(pick < 0.0f)) ? -1.0f : 0.5f * pick / a;
 #endif
     return rl_paraboloid_roots(a, b, c);
 }
@@ -433,12 +433,34 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
     float t_in = -INF, t_out = INF;  // carry the plane number in their low 3 bits
     float min_dn = INF, min_ta = INF;
     uint32_t min_pos = 0xffffffffu;  // the smallest positive ta: positive floats order like their bits, negative ones are larger
+#ifndef RL_W_P
+#define RL_W_P 1 // rl_hex_prism_fast on the device: the next plane's records in flight behind this plane's arithmetic (A/B builds set 0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && RL_W_P
+    RlF4 rec_n = pr[0], rec_off = pr[1];
+#endif
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int k = 0; k < 8; ++k) {
+#if defined(__HIP_DEVICE_COMPILE__) && RL_W_P
+        // The next plane's two records are requested before this plane's arithmetic and waited for behind it: one plane
+        // in flight, not sixteen loads at once (the round would spill) and not eight LDS round trips in a row either.
+        const RlF4 cur_n = rec_n, cur_off = rec_off;
+        if (k < 7) {
+            rec_n = pr[2 * k + 2];
+            rec_off = pr[2 * k + 3];
+        }
+        asm volatile("" ::: "memory");
+        const RlF3 n = rl_xyz(cur_n);
+        const RlF3 lo = rl_sub(o, rl_xyz(cur_off));
+#else
         const RlF3 n = rl_xyz(pr[2 * k]);
         const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k + 1]));
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !RL_W_P
+        asm volatile("" ::: "memory"); // one plane at a time: without this the scheduler issues the sixteen record loads first and the round spills
+#endif
         const float dnk = rl_dot(n, d);   // exactly the reference's two dot products (geometry.rs:59-62)
         const float nm = rl_dot(n, lo);
         const float tk = rl_u2f((rl_f2u(-nm * rl_rcp_approx(dnk)) & 0xfffffff8u) | (uint32_t)k);
@@ -451,10 +473,6 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
         min_ta = fminf(min_ta, fabsf(tk));
         const uint32_t tb = rl_f2u(tk);
         min_pos = tb < min_pos ? tb : min_pos;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // one plane at a time: without this the scheduler issues the sixteen record loads first and the round spills
-        asm volatile("" ::: "memory");
-#endif
     }
     const float U64 = 3.814697265625e-06f; // 64 * 2^-24
     const float d1 = fabsf(d.x) + fabsf(d.y) + fabsf(d.z);
@@ -667,7 +685,7 @@ RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) 
     const float e_fast = __builtin_amdgcn_exp2f(intensity * -28.853901f); // -20 log2(e)
     const float gap = unit * 0.85f - continue_chance * (1.0f - e_fast);
     const bool undecided = !(fabsf(gap) >= 2.0e-5f) || !(intensity >= 0.0f && intensity <= 1.0f);
-    if (__builtin_amdgcn_ballot_w64(undecided) == 0) return gap > 0.0f;
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(undecided) == 0)) return gap > 0.0f;
 #endif
     return unit * 0.85f > continue_chance * (1.0f - rl_expf(intensity * -20.0f));
 }

@@ -29,7 +29,18 @@
 #include "rl_core.h"
 
 #define RL_BLOCK 256        // streaming kernels (plot, gather, tonemap)
+#ifndef RL_TRACE_BLOCK
 #define RL_TRACE_BLOCK 1024 // trace kernel: one workgroup of 16 waves per CU shares one LDS copy of the scene
+#endif
+#ifndef RL_W_S
+#define RL_W_S 1 // ring-S rounds of the plain launches: the children's bounds requested ahead of the cross-lane fetch (A/B builds set 0)
+#endif
+#ifndef RL_W_B
+#define RL_W_B 1 // ring-B rounds: the sphere record, its radius^2 and its object likewise
+#endif
+#ifndef RL_W_M
+#define RL_W_M 1 // cluster-member rounds: the first member likewise
+#endif
 #define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills) in large launches
 
 struct RlSceneLayout {
@@ -41,6 +52,7 @@ struct RlSceneLayout {
     uint32_t off_sphere_r2;                    // blob offset of RlSceneView::sphere_r2
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
     uint32_t group_gc;                         // RlFlatScene::group_gc: clusters per group of the cull table
+    uint32_t small_ordered;                    // the paraboloids' objects all precede the planes' and circles' (rl_scan_wave: one compare per candidate)
     // Records [off_planes, off_objects) of the blob are the TABLES -- planes, paraboloids, prisms, the cull table, the camera:
     // everything a scan reads with wave-uniform addresses or once per (group, ray) / (prism, ray) pair, 10-40 KB whatever the
     // scene's size.  The spheres in front of them and the per-object arrays behind them grow with the scene: one too large for
@@ -309,8 +321,8 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-template <bool CYL, bool SPLIT, bool UNROLL_S>
-__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, float sv_cull_cmax2,
+template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S>
+__device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, uint32_t small_ordered, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
@@ -326,7 +338,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // spilled to lanes of a vector register and read back with v_readlane (half-rate VALU).  Opaque copies: the flags are
     // one s_cmp each where they are used.
     uint32_t n_parabs = sv.n_parabs, n_planes = sv.n_planes, n_direct = sv.n_direct, cluster_k = sv.cluster_k;
-    asm volatile("" : "+s"(n_parabs), "+s"(n_planes), "+s"(n_direct), "+s"(cluster_k), "+s"(n_cluster_groups), "+s"(n_prism_groups), "+s"(group_gc));
+    asm volatile("" : "+s"(n_parabs), "+s"(n_planes), "+s"(n_direct), "+s"(cluster_k), "+s"(n_cluster_groups), "+s"(n_prism_groups), "+s"(group_gc), "+s"(small_ordered));
 
     // Paraboloids, planes and circles: a handful of records, evaluated in registers.
     RlHit best;
@@ -334,30 +346,43 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     best.obj = RL_HIT_NONE;
     best.sub = 0;
     RL_T0(t_small);
-    for (uint32_t i = 0; i < n_parabs; ++i) {
-        const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];
-        const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
-        const uint32_t obj = rl_f2u(r0.w);
-        if (!(t < 0.0f) && rl_nearer(t, obj, best)) {
-            best.t = t;
-            best.obj = obj;
-        }
+    // scene.rs:51 keeps the FIRST object among equal distances: `t < best.t || (t == best.t && obj < best.obj)` in any evaluation
+    // order.  Both record lists are in object order (rl_scene.cpp), so a plain `t < best.t` decides within each; it also decides
+    // between them when every paraboloid's object precedes every plane's (RlSceneLayout::small_ordered, the built-in scenes) --
+    // two compares, two mask operations and a branch less per candidate than the general form, which other scenes take.
+#define RL_SMALL_PRIMITIVES(NEARER)                                                                   \
+    for (uint32_t i = 0; i < n_parabs; ++i) {                                                         \
+        const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];       \
+        const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);                  \
+        const uint32_t obj = rl_f2u(r0.w);                                                            \
+        if (!(t < 0.0f) && NEARER(t, obj, best)) {                                                    \
+            best.t = t;                                                                               \
+            best.obj = obj;                                                                           \
+        }                                                                                             \
+    }                                                                                                 \
+    for (uint32_t i = 0; i < n_planes; ++i) {                                                         \
+        const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];                                  \
+        float dn;                                                                                     \
+        const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);                              \
+        bool hit = t > 0.0f;                                                                          \
+        if (hit && r0.w >= 0.0f) {                                                                    \
+            const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));                            \
+            hit = rl_dot(dp, dp) <= r0.w;                                                             \
+        }                                                                                             \
+        const uint32_t obj = rl_f2u(r1.w);                                                            \
+        if (hit && NEARER(t, obj, best)) {                                                            \
+            best.t = t;                                                                               \
+            best.obj = obj;                                                                           \
+        }                                                                                             \
     }
-    for (uint32_t i = 0; i < n_planes; ++i) {
-        const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];
-        float dn;
-        const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
-        bool hit = t > 0.0f;
-        if (hit && r0.w >= 0.0f) {
-            const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
-            hit = rl_dot(dp, dp) <= r0.w;
-        }
-        const uint32_t obj = rl_f2u(r1.w);
-        if (hit && rl_nearer(t, obj, best)) {
-            best.t = t;
-            best.obj = obj;
-        }
+#define RL_NEARER_ORDERED(T, OBJ, BEST) ((T) < (BEST).t)
+    if (small_ordered != 0u) {
+        RL_SMALL_PRIMITIVES(RL_NEARER_ORDERED)
+    } else {
+        RL_SMALL_PRIMITIVES(rl_nearer)
     }
+#undef RL_NEARER_ORDERED
+#undef RL_SMALL_PRIMITIVES
     keys[lane] = ((unsigned long long)rl_f2u(best.t) << 32) |
                  (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
     RL_T1(RL_ST_T_SMALL, t_small);
@@ -371,19 +396,26 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t e = ring_b[(b_head + lane) & 127u];
         const uint32_t owner = e & 63u;
         const uint32_t pos = e >> 6;
+        // (the record depends on the ring entry alone: its loads are issued ahead of the cross-lane fetch, whose wait then
+        // covers both -- a wave's time is a third waiting for LDS round trips; entries beyond the round are
+        // stale but name records that exist)
+        RlF4 s;
+        float s_r2;     // (a clustered sphere's s.w is its cull term)
+        uint32_t s_obj;
+        if (RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos], s_obj = sv.sphere_obj[pos];
         float ox, oy, oz, dx, dy, dz;
         rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ox, oy, oz, dx, dy, dz);
         if (lane < count) {
-            const RlF4 s = sph[pos];
+            if (!RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos];
             const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
             const float dd = dx * cox + dy * coy + dz * coz;
-            const float c = (cox * cox + coy * coy + coz * coz) - sv.sphere_r2[pos]; // (a clustered sphere's s.w is its cull term)
+            const float c = (cox * cox + coy * coy + coz * coz) - s_r2;
             const float q = dd * dd - c;
             const float sq = rl_sqrtf(q, true); // |q| is rooted: a miss of the pre-tested pair (q < 0, geometry.rs:213-215) is tested for itself
             const float t1 = dd - sq;
             const float t2 = dd + sq;
             if (q >= 0.0f && t1 > 0.0f && t1 < t2) {
-                const uint32_t obj = sv.sphere_obj[pos];
+                const uint32_t obj = RL_W_B ? s_obj : sv.sphere_obj[pos];
                 __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)(obj << 3),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
@@ -406,7 +438,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (m != 0) {                                                                               \
             if (cand) ring_b[rl_mbcnt_from(m, b_tail) & 127u] = ((POS) << 6) | (OWNER);               \
             b_tail += (uint32_t)__popcll(m);                                                        \
-            if (b_tail - b_head >= 64u) {                                                           \
+            if (RL_UNLIKELY(b_tail - b_head >= 64u)) {                                                           \
                 process_spheres(64u);                                                               \
                 b_head += 64u;                                                                      \
             }                                                                                       \
@@ -463,9 +495,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
         uint32_t first = sv.cluster_base + (cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
         if (split) first += (lane >> 5) * (n_members >> 1);
+        RlF4 mb;
+        if (RL_W_M) mb = sph[first]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
         float r_far;
         rl_fetch_cull_ray(owner, cr, far, r, r_far);
+        if (!RL_W_M) mb = sph[first];
         // The members that pass are collected as one bit per member in a lane-private mask (one v_alignbit per member: shift
         // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
         // per pair, so two or three steps replace ten ballot / count / write sequences.
@@ -475,7 +510,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // from -- unrolled, the members' addresses are immediates -- and n_members otherwise (a build that forces another size: rolled, ~2 % slower).
 #define RL_MEMBERS(N)                                                                                                    \
         {                                                                                                                \
-            RlF4 mb = sph[first];                                                                                        \
             uint32_t failed = 0; /* one bit per member: the sign of the test's margin, shifted in with one v_alignbit */  \
             for (uint32_t j = 0; j < (N); ++j) {                                                                         \
                 const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
@@ -497,7 +531,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             if (passed != 0u) ring_b[rl_mbcnt_from(any, b_tail) & 127u] = ((first + j) << 6) | owner;
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;
-            if (b_tail - b_head >= 64u) {
+            if (RL_UNLIKELY(b_tail - b_head >= 64u)) {
                 process_spheres(64u);
                 b_head += 64u;
             }
@@ -515,9 +549,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // ---- ring S round.  PROCESS_A(count) runs a ring-A round; ITEM_BASE turns a cull-table index into the
     // cluster / prism number.
     /* one child of the pair's group: its bound (and, CYL, its cylinder) against the owner's ray; the pairs that pass go to ring A */ \
-#define RL_GROUP_CHILD(J, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                         \
+#define RL_GROUP_CHILD(J, COUNT, G, ITEM_BASE, PROCESS_A, CYL) RL_GROUP_CHILD_OF(cull[first + (J)], J, COUNT, G, ITEM_BASE, PROCESS_A, CYL)
+#define RL_GROUP_CHILD_OF(BND, J, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                 \
     {                                                                                                   \
-        const RlF4 bnd = cull[first + (J)];                                                             \
+        const RlF4 bnd = (BND);                                                                         \
         const bool pass = rl_cull_pass(r, bnd, r_far);                                                  \
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                           \
         if (m != 0) {                                                                                   \
@@ -529,7 +564,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #define RL_PUSH_false(ENTRY, PROCESS_A)                                                                 \
     if (pass) ring_a[rl_mbcnt_from(m, a_tail) & 127u] = (ENTRY);                                        \
     a_tail += (uint32_t)__popcll(m);                                                                    \
-    if (a_tail - a_head >= 64u) {                                                                       \
+    if (RL_UNLIKELY(a_tail - a_head >= 64u)) {                                                                       \
         PROCESS_A(64u);                                                                                 \
         a_head += 64u;                                                                                  \
     }
@@ -538,7 +573,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     if (CYL) {                                                                                          \
         if (pass) ring_b[rl_mbcnt_from(m, b_tail) & 127u] = (ENTRY);                                    \
         b_tail += (uint32_t)__popcll(m);                                                                \
-        if (b_tail - b_head >= 64u) {                                                                   \
+        if (RL_UNLIKELY(b_tail - b_head >= 64u)) {                                                                   \
             process_cylinders(64u);                                                                     \
             b_head += 64u;                                                                              \
         }                                                                                               \
@@ -558,6 +593,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t e = ring_s[(s_head + lane) & 127u];                                              \
         const uint32_t owner = e & 63u;                                                                 \
         const uint32_t first = (ITEM_BASE) + (G) * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
+        /* (UNROLL_S: the children's bounds depend on the ring entry alone and are requested ahead of the cross-lane fetch, \
+           whose wait covers them -- three LDS round trips less per round; the table has slack behind its last group) */ \
+        RlF4 bnd_[4];                                                                                   \
+        if (UNROLL_S && HOIST_S) {                                                                       \
+            bnd_[0] = cull[first]; bnd_[1] = cull[first + 1u]; bnd_[2] = cull[first + 2u];              \
+            if ((G) == 4u) bnd_[3] = cull[first + 3u];                                                  \
+        }                                                                                               \
         RlCullRay r;                                                                                    \
         float r_far;                                                                                    \
         rl_fetch_cull_ray(owner, cr, far, r, r_far);                                                    \
@@ -565,7 +607,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (UNROLL_S) {                                                                                 \
             _Pragma("unroll") for (uint32_t j = 0; j < 4u; ++j) {                                       \
                 if (j >= (G)) break; /* groups hold 3 or 4 bounds */                                    \
-                RL_GROUP_CHILD(j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                  \
+                if (HOIST_S) RL_GROUP_CHILD_OF(bnd_[j], j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)          \
+                else RL_GROUP_CHILD(j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                             \
             }                                                                                           \
         } else {                                                                                        \
             _Pragma("nounroll") for (uint32_t j = 0; j < (G); ++j) RL_GROUP_CHILD(j, COUNT, G, ITEM_BASE, PROCESS_A, CYL) \
@@ -588,7 +631,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             if (m != 0) {                                                                               \
                 if (pass) ring_s[rl_mbcnt_from(m, s_tail) & 127u] = (g << 6) | lane; /* group number within its kind */ \
                 s_tail += (uint32_t)__popcll(m);                                                        \
-                if (s_tail - s_head >= 64u) {                                                           \
+                if (RL_UNLIKELY(s_tail - s_head >= 64u)) {                                                           \
                     RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                   \
                     s_head += 64u;                                                                      \
                 }                                                                                       \
@@ -659,15 +702,16 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();
         const uint32_t e = ring_b[(b_head + lane) & 127u];
         const uint32_t owner = e & 63u;
+        const RlF4* cy = prism_cyl + 2u * (lane < count ? (e >> 6) : 0u);
+        const RlF4 cy0 = cy[0], cy1 = cy[1]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
         rl_fetch6(owner, cr.d.x, cr.d.y, cr.d.z, cr.m.x, cr.m.y, cr.m.z, r.d.x, r.d.y, r.d.z, r.m.x, r.m.y, r.m.z);
-        const RlF4* cy = prism_cyl + 2u * (lane < count ? (e >> 6) : 0u);
-        const bool pass = lane < count && rl_cyl_pass(r, cy[0], rl_xyz(cy[1]));
+        const bool pass = lane < count && rl_cyl_pass(r, cy0, rl_xyz(cy1));
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
             if (pass) ring_a[rl_mbcnt_from(m, a_tail) & 127u] = e;
             a_tail += (uint32_t)__popcll(m);
-            if (a_tail - a_head >= 64u) {
+            if (RL_UNLIKELY(a_tail - a_head >= 64u)) {
                 process_prisms(64u);
                 a_head += 64u;
             }
@@ -680,6 +724,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_GROUP_CULLS
 #undef RL_GROUP_ROUND
 #undef RL_GROUP_CHILD
+#undef RL_GROUP_CHILD_OF
 #undef RL_PUSH_CYL
 #undef RL_PUSH_false
     if (CYL && b_tail != b_head) {
@@ -722,13 +767,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 // CYL: the scene's prisms carry a second bound (RlFlatScene::prism_cylinders) -- a compile-time switch so that scenes
 // without it run exactly the code they ran before it existed.
 template <int STAGE, bool FUSED, bool OPEN, bool CYL>
-// At most 120 VGPRs: four waves per SIMD then leave 32 of the 512 registers, which is what lets the small kernels of
-// the other units (plot, gather, tonemap, clears) run BESIDE a resident trace kernel instead of behind it.
-__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay,
-                                                                  RlTraceJob job, RlMappedPhoton* __restrict__ photons,
-                                                                  float* __restrict__ plot,
-                                                                  unsigned long long* __restrict__ queue,
-                                                                  const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
+__device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, const RlSceneLayout& lay, const RlTraceJob& job, RlMappedPhoton* __restrict__ photons,
+                                              float* __restrict__ plot, unsigned long long* __restrict__ queue, const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
     extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
     const RlF4* base = scene; // the tables
     const RlF4* big = scene;  // the per-sphere and per-object arrays
@@ -908,6 +948,56 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
             settle();
             flush(3000u);
         }
+#if defined(RL_EXP_EXTRA)
+        // sensitivity probe (timing only, tools/ab3.sh): what does one more instruction of a kind cost the kernel?
+        {
+            uint32_t xs = lane, xv = lane;
+#if RL_EXP_EXTRA == 1 // 256 scalar instructions
+            uint32_t ss = 1;
+#pragma unroll
+            for (int k = 0; k < 256; ++k) asm volatile("s_add_u32 %0, %0, 3" : "+s"(ss));
+            xs = ss;
+#elif RL_EXP_EXTRA == 2 // 256 vector instructions (four chains)
+            uint32_t a = lane, b = lane + 1, c = lane + 2, d = lane + 3;
+#pragma unroll
+            for (int k = 0; k < 64; ++k) asm volatile("v_add_u32 %0, 3, %0\n\tv_add_u32 %1, 5, %1\n\tv_add_u32 %2, 7, %2\n\tv_add_u32 %3, 9, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            xv = a ^ b ^ c ^ d;
+#elif RL_EXP_EXTRA == 3 // 16 exposed LDS round trips
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("ds_read_b32 %0, %0\n\ts_waitcnt lgkmcnt(0)\n\tv_and_b32 %0, 0xfc, %0" : "+v"(xv) : : "memory");
+#elif RL_EXP_EXTRA == 4 // 256 s_nop 0
+#pragma unroll
+            for (int k = 0; k < 256; ++k) asm volatile("s_nop 0");
+#elif RL_EXP_EXTRA == 5 // 256 vector instructions in ONE dependent chain
+#pragma unroll
+            for (int k = 0; k < 256; ++k) asm volatile("v_add_u32 %0, 3, %0" : "+v"(xv));
+#elif RL_EXP_EXTRA == 8 // 64 taken branches
+#pragma unroll
+            for (int k = 0; k < 64; ++k) asm volatile("s_branch 0");
+#elif RL_EXP_EXTRA == 9 // 64 conditional branches that are not taken
+            asm volatile("s_cmp_eq_u32 0, 1");
+#pragma unroll
+            for (int k = 0; k < 64; ++k) asm volatile("s_cbranch_scc1 0");
+#elif RL_EXP_EXTRA == 10 // 4 batches of nine cross-lane fetches with one wait each
+            {
+                float t0 = (float)lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    RlCullRay in, out;
+                    in.d = rl_f3(t0, t0 + 1.0f, t0 + 2.0f); in.m = rl_f3(t0 + 3.0f, t0 + 4.0f, t0 + 5.0f); in.p = t0 + 6.0f; in.q = t0 + 7.0f; in.len = 0.0f;
+                    float of;
+                    rl_fetch_cull_ray((lane * 7u + 3u) & 63u, in, t0 + 8.0f, out, of);
+                    t0 = out.d.x + out.d.y + out.d.z + out.m.x + out.m.y + out.m.z + out.p + out.q + of;
+                }
+                xv = rl_f2u(t0);
+            }
+#elif RL_EXP_EXTRA == 11 // 64 s_and_saveexec / s_or exec pairs
+#pragma unroll
+            for (int k = 0; k < 64; ++k) asm volatile("s_and_saveexec_b64 s[2:3], exec\n\ts_or_b64 exec, exec, s[2:3]" ::: "s2", "s3");
+#endif
+            if (xs == 0xdeadbeefu || xv == 0xdeadbeefu) segments += 1; // keep the probe alive
+        }
+#endif
         // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
         RL_T0(t_refill);
         for (;;) {
@@ -1123,7 +1213,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         }
         // (ring-S rounds unrolled wherever the cull table is in LDS -- except in the fused open launches of a tables-only scene, the
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE == RL_STAGE_ALL || (STAGE == RL_STAGE_TABLES && !(FUSED && OPEN))>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), !OPEN && RL_W_S>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
@@ -1210,7 +1300,7 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
                     ended_on_emitter = false;
                 }
                 e_tail += (uint32_t)__popcll(m);
-                if (e_tail - e_head >= 64u) {
+                if (RL_UNLIKELY(e_tail - e_head >= 64u)) {
                     process_emitted(64u);
                     e_head += 64u;
                 }
@@ -1239,6 +1329,27 @@ __global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(6
         atomicAdd(&queue[1], (unsigned long long)s);
         atomicAdd(&queue[2], (unsigned long long)d);
     }
+}
+
+// The two entry points.  Four waves per SIMD either way (one workgroup of 16 waves per CU).
+//   * plain launches -- every bulk launch, the bench -- may use all 128 vector registers a wave can have at that occupancy;
+//   * OPEN launches stay resident while the host appends calls to them, so they keep to 120: four waves per SIMD then leave 32 of
+//     the 512 registers per lane, which is what lets the small kernels of the other units (plot, gather, tonemap, clears) run
+//     BESIDE a resident trace kernel instead of behind it.
+// (amdgpu_num_vgpr counts in units of two registers on this target.)
+template <int STAGE, bool FUSED, bool CYL>
+__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(64))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
+                                                                                                       RlMappedPhoton* __restrict__ photons, float* __restrict__ plot,
+                                                                                                       unsigned long long* __restrict__ queue, const RlJobEntry* jobs,
+                                                                                                       RlOpenDev* od, RlOpenCtl* ctl) {
+    rl_trace_body<STAGE, FUSED, false, CYL>(scene, lay, job, photons, plot, queue, jobs, od, ctl);
+}
+template <int STAGE, bool FUSED, bool CYL>
+__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel_open(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
+                                                                                                            RlMappedPhoton* __restrict__ photons, float* __restrict__ plot,
+                                                                                                            unsigned long long* __restrict__ queue, const RlJobEntry* jobs,
+                                                                                                            RlOpenDev* od, RlOpenCtl* ctl) {
+    rl_trace_body<STAGE, FUSED, true, CYL>(scene, lay, job, photons, plot, queue, jobs, od, ctl);
 }
 
 // PlotUnit::plot (plot_unit.rs:87-95) for the un-fused path: one photon per thread.

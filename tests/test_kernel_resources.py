@@ -45,11 +45,16 @@ def usage(tmp_path_factory):
     return kernels
 
 
+TRACE_NAME = r"_Z(?:15rl_trace_kernel|20rl_trace_kernel_open)ILi([012])ELb([01])ELb([01])E"   # <stage, fused, cylinders>
+
+
 def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage):
     trace = {k: v for k, v in usage.items() if "rl_trace_kernel" in k and k != "__asm__"}
     assert len(trace) == 24                                           # (nothing / the tables / the whole scene) staged in LDS x fused / un-fused x plain / open x prisms with / without a second bound
     for name, u in trace.items():
-        assert u["VGPRs"] <= 120 and u.get("AGPRs", 0) == 0, (name, u)
+        # OPEN launches stay resident while the other units' kernels run: 120 registers leave those their 32.  Plain (bulk)
+        # launches end by themselves and may use all 128 a wave can have at four waves per SIMD (round 5).
+        assert u["VGPRs"] <= (120 if "rl_trace_kernel_open" in name else 128) and u.get("AGPRs", 0) == 0, (name, u)
         assert u["Occupancy"] == 4, (name, u)
     # nothing spills to memory in ANY of the variants -- the OPEN ones are what the drop-in's blocking calls run --
     # and since round 4 (VERDICT r03 #1a) no scalar register spills at all in the variants that stage the scene in LDS: the
@@ -59,14 +64,16 @@ def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage
     # in scalar registers; what does not fit stays bounded.
     for name, u in trace.items():
         assert u["ScratchSize"] == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
-        stage = int(re.search(r"ILi([012])ELb([01])ELb([01])ELb([01])E", name).group(1))   # RL_STAGE_NONE / TABLES / ALL
+        stage = int(re.search(TRACE_NAME, name).group(1))   # RL_STAGE_NONE / TABLES / ALL
         assert u["SGPRs Spill"] == 0 if stage == 2 else u["SGPRs Spill"] <= 24, (name, u)
     # ... and hence no v_readlane / v_writelane traffic from spills in the LDS variants (what is left reads a wave-uniform
     # value out of a vector register on purpose: v_readfirstlane and a handful of v_readlane of the stash hand-out)
     text = usage["__asm__"]
-    for m in re.finditer(r"\n(_Z15rl_trace_kernelILi2ELb[01]ELb[01]ELb[01]E\w+):(.*?)s_endpgm", text, re.S):
-        assert len(re.findall(r"v_writelane_b32", m.group(2))) == 0, m.group(1)
-        assert len(re.findall(r"v_readlane_b32", m.group(2))) <= 4, m.group(1)
+    bodies = re.findall(r"\n(_Z(?:15rl_trace_kernel|20rl_trace_kernel_open)ILi2ELb[01]ELb[01]E\w+):(.*?)s_endpgm", text, re.S)
+    assert len(bodies) == 8
+    for name, body in bodies:
+        assert len(re.findall(r"v_writelane_b32", body)) == 0, name
+        assert len(re.findall(r"v_readlane_b32", body)) <= 4, name
 
 
 def test_the_small_kernels_fit_beside_it(usage):
@@ -82,8 +89,8 @@ def test_open_variants_wait_for_their_results_before_counting_them(usage):
     site it is inlined or merged into), and in none of the plain ones (which never count per call)."""
     text = usage["__asm__"]
     bodies = {}
-    for m in re.finditer(r"\n(_Z15rl_trace_kernelILi[012]ELb[01]ELb([01])ELb[01]E\w+):(.*?)s_endpgm", text, re.S):
-        bodies[m.group(1)] = (m.group(2) == "1", m.group(3))
+    for m in re.finditer(r"\n(_Z(15rl_trace_kernel|20rl_trace_kernel_open)ILi[012]ELb[01]ELb[01]E\w+):(.*?)s_endpgm", text, re.S):
+        bodies[m.group(1)] = (m.group(2).endswith("open"), m.group(3))
     assert len(bodies) == 24
     for name, (is_open, body) in bodies.items():
         n = len(re.findall(r"s_waitcnt vmcnt\(0\) ; rl_settle", body))
