@@ -212,12 +212,14 @@ TraceKernel trace_kernel_variant(int stage, bool fused, bool open, bool cyl) {
 int stage_of(const RlScene* scene, int fetch, size_t scratch_bytes, size_t* bytes) {
     *bytes = 0;
     if (fetch != RL_FETCH_LDS) return RL_STAGE_NONE;
-    if (scene->staged_bytes + scratch_bytes <= 160 * 1024) {
-        *bytes = scene->staged_bytes;
+    // (what is staged is rounded up to 512 bytes: the waves' scratch behind it is 512-byte aligned, rl_trace_body)
+    const size_t all = (scene->staged_bytes + 511) & ~(size_t)511, tables = (scene->tables_bytes + 511) & ~(size_t)511;
+    if (all + scratch_bytes <= 160 * 1024) {
+        *bytes = all;
         return RL_STAGE_ALL;
     }
-    if (scene->tables_bytes + scratch_bytes <= 160 * 1024) {
-        *bytes = scene->tables_bytes;
+    if (tables + scratch_bytes <= 160 * 1024) {
+        *bytes = tables;
         return RL_STAGE_TABLES;
     }
     return RL_STAGE_NONE;
@@ -464,7 +466,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.n_planes = (uint32_t)(fs.planes.size() / 2);
     lay.n_parabs = (uint32_t)(fs.parabs.size() / 3);
     lay.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
-    lay.n_objects = (uint32_t)(fs.objects.size() / 2);
+    lay.n_objects = (uint32_t)fs.objects.size();
 
     RlScene* s = new (std::nothrow) RlScene();
     if (!s) return fail(RL_E_INVALID, "out of host memory");

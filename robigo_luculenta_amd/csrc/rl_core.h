@@ -427,6 +427,9 @@ RL_HD float rl_rcp_approx(float x) {
 #endif
 }
 
+// PIPELINED (device): the next plane's records are requested behind this plane's arithmetic (eight more live registers: the
+// plain launches, which have them; the open ones load plane by plane).
+template <bool PIPELINED = true>
 RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
     const float INF = __builtin_inff();
     float dn[8], ta[8];
@@ -436,30 +439,33 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
 #ifndef RL_W_P
 #define RL_W_P 1 // rl_hex_prism_fast on the device: the next plane's records in flight behind this plane's arithmetic (A/B builds set 0)
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && RL_W_P
-    RlF4 rec_n = pr[0], rec_off = pr[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    RlF4 rec_n, rec_off;
+    if (PIPELINED && RL_W_P) rec_n = pr[0], rec_off = pr[1];
 #endif
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int k = 0; k < 8; ++k) {
-#if defined(__HIP_DEVICE_COMPILE__) && RL_W_P
+#if defined(__HIP_DEVICE_COMPILE__)
         // The next plane's two records are requested before this plane's arithmetic and waited for behind it: one plane
         // in flight, not sixteen loads at once (the round would spill) and not eight LDS round trips in a row either.
-        const RlF4 cur_n = rec_n, cur_off = rec_off;
-        if (k < 7) {
-            rec_n = pr[2 * k + 2];
-            rec_off = pr[2 * k + 3];
+        RlF4 cur_n, cur_off;
+        if (PIPELINED && RL_W_P) {
+            cur_n = rec_n, cur_off = rec_off;
+            if (k < 7) {
+                rec_n = pr[2 * k + 2];
+                rec_off = pr[2 * k + 3];
+            }
+        } else {
+            cur_n = pr[2 * k], cur_off = pr[2 * k + 1];
         }
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory"); // (one plane at a time: without this the scheduler issues the sixteen record loads first)
         const RlF3 n = rl_xyz(cur_n);
         const RlF3 lo = rl_sub(o, rl_xyz(cur_off));
 #else
         const RlF3 n = rl_xyz(pr[2 * k]);
         const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k + 1]));
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !RL_W_P
-        asm volatile("" ::: "memory"); // one plane at a time: without this the scheduler issues the sixteen record loads first and the round spills
 #endif
         const float dnk = rl_dot(n, d);   // exactly the reference's two dot products (geometry.rs:59-62)
         const float nm = rl_dot(n, lo);
@@ -667,7 +673,7 @@ RL_HD float rl_clamp999(float x) { // material.rs:288-292
 // EmissiveMaterial::get_intensity scaled by the path's intensity (trace_unit.rs:99-101, material.rs:101-105)
 // for a path that ended on emitter `obj`.
 RL_HD float rl_emission(const RlSceneView& sv, float intensity, float wavelength, uint32_t obj) {
-    const RlF4 ob = sv.objects[2 * obj + 1];
+    const RlF4 ob = sv.objects[obj];
     return intensity * ((float)rl_boltzmann((double)wavelength, (double)ob.x) * ob.y);
 }
 
@@ -741,16 +747,15 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
                     const RlHit& hit, float* value, uint32_t* emitter, float* pair_scratch = nullptr) {
     *value = 0.0f;
     if (hit.obj == RL_HIT_NONE) return RL_PATH_ENDED; // The Void
-    const RlF4 oa = sv.objects[2 * hit.obj];
-    const RlF4 ob = sv.objects[2 * hit.obj + 1];
-    const uint32_t kinds = rl_f2u(oa.x);
-    const uint32_t surface_kind = kinds & 0xffu;
-    const uint32_t material_kind = kinds >> 8;
+    const RlF4 ob = sv.objects[hit.obj];
+    const uint32_t kinds = rl_f2u(ob.w);
+    const uint32_t surface_kind = rl_object_surface(kinds);
+    const uint32_t material_kind = rl_object_material(kinds);
     if (material_kind == RL_MATERIAL_BLACK_BODY) {
         *emitter = hit.obj;
         return RL_PATH_ENDED_ON_EMITTER;
     }
-    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_f2u(oa.y));
+    const RlIsect is = rl_finish_hit(sv, p->origin, p->direction, hit, surface_kind, rl_object_group(kinds));
     const RlRngBlock rb = rl_rng_block(seed, stream, path_index, 2u + p->bounce);
     const RlF3 in_dir = p->direction;
     // Mirror direction about the surface (vector3.rs:91-93): total internal reflection, the bubble's reflection

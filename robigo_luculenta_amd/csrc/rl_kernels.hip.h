@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 #include "rl_cie1931.h"
 #include "rl_core.h"
 
@@ -264,33 +266,52 @@ __device__ __forceinline__ bool rl_cyl_pass(const RlCullRay& r, RlF4 c, RlF3 a) 
     return !(w * w > radius * radius * cr2);
 }
 
-// The owner lane's cull terms (and far bound) for a round: nine values, one wait.
-__device__ __forceinline__ void rl_fetch_cull_ray(uint32_t owner, const RlCullRay& cr, float far, RlCullRay& r, float& r_far) {
-    const uint32_t addr = owner << 2;
-    asm volatile("ds_bpermute_b32 %0, %9, %10\n\tds_bpermute_b32 %1, %9, %11\n\tds_bpermute_b32 %2, %9, %12\n\t"
-                 "ds_bpermute_b32 %3, %9, %13\n\tds_bpermute_b32 %4, %9, %14\n\tds_bpermute_b32 %5, %9, %15\n\t"
-                 "ds_bpermute_b32 %6, %9, %16\n\tds_bpermute_b32 %7, %9, %17\n\tds_bpermute_b32 %8, %9, %18\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.d.x), "=&v"(r.d.y), "=&v"(r.d.z), "=&v"(r.m.x), "=&v"(r.m.y), "=&v"(r.m.z), "=&v"(r.p), "=&v"(r.q), "=&v"(r_far)
-                 : "v"(addr), "v"(cr.d.x), "v"(cr.d.y), "v"(cr.d.z), "v"(cr.m.x), "v"(cr.m.y), "v"(cr.m.z), "v"(cr.p), "v"(cr.q), "v"(far)
-                 : "memory");
-    r.len = 0.0f;
-}
-
-// Per-wave LDS scratch of the scan: the merge keys and three rings of deferred work.
+// Per-wave LDS scratch: the merge keys, three rings of deferred work, the rays' cull terms, the camera-ray stash and the
+// emitter queue.  8 KB, a multiple of 512 bytes (RL_RING_SLOT).
 struct RlWaveScratch {
     unsigned long long key[64]; // (bits(distance) << 32) | (object << 3 | half-space), min-merged
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
     uint32_t ring_s[128];       // (group index << 6) | owner lane: second level of the cull table
-    // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior, then
-    // the path's index in its RNG stream (lo, hi; both ~0 = no path).  Refilled with all 64 lanes busy.
+    // The cull terms of the wave's 64 rays, one 32-byte slot per lane: {d.xyz, p}, {m.xyz, q} (RlCullRay), and the far bounds.
+    // Written by every lane once per scan; a round's lane reads the slot of its pair's OWNER with two 16-byte loads and one
+    // 4-byte load.  Rounds 1-4 fetched the nine values across lanes with nine ds_bpermute_b32 -- ~430 cycles of a wave's
+    // time per round measured in the kernel (tools/ab3.sh, the RL_EXP_EXTRA probes), against ~90 for the gathers; five such
+    // rounds per iteration.  The room came from the emitter queue (128 -> 64 slots), the stash's path indices (derived
+    // now) and the object table (one record per object).
+    float terms[64][8];
+    float far[64];
+    // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior.  Refilled with all 64 lanes
+    // busy; slot s holds path (stash_path0 + s) of the RNG stream, the first stash_valid slots hold a path at all
+    // (wave-uniform registers of rl_trace_body).
     float stash[10][64];
-    uint32_t stash_off[2][64];
     // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
-    // until 64 of them can be evaluated and splatted with a full exec mask.
-    float emit[5][128];
+    // until (about) 64 of them can be evaluated and splatted with a full exec mask.
+    float emit[5][64];
 };
+static_assert(sizeof(RlWaveScratch) == 8192, "rl_scan_wave's ring addressing wants the wave's scratch 512-byte aligned");
+
+typedef float RlV4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) RlV4 RlLdsV4;
+typedef __attribute__((address_space(3))) float RlLdsF;
+// A lane's cull terms (and far bound) into its slot of the wave's scratch, once per scan ...
+__device__ __forceinline__ void rl_store_cull_ray(RlWaveScratch* ws, uint32_t lane, const RlCullRay& cr, float far) {
+    RlLdsV4* slots = (RlLdsV4*)&ws->terms[0][0];
+    slots[2u * lane] = (RlV4){cr.d.x, cr.d.y, cr.d.z, cr.p};
+    slots[2u * lane + 1u] = (RlV4){cr.m.x, cr.m.y, cr.m.z, cr.q};
+    ((RlLdsF*)&ws->far[0])[lane] = far;
+}
+// ... and the OWNER lane's, for a round: two 16-byte gathers and a 4-byte one (the caller has passed a wave sync since the store).
+__device__ __forceinline__ void rl_fetch_cull_ray(RlWaveScratch* ws, uint32_t owner, RlCullRay& r, float& r_far) {
+    const RlLdsV4* slots = (const RlLdsV4*)&ws->terms[0][0];
+    const RlV4 a = slots[2u * owner], b = slots[2u * owner + 1u];
+    r_far = ((const RlLdsF*)&ws->far[0])[owner];
+    r.d = rl_f3(a.x, a.y, a.z);
+    r.p = a.w;
+    r.m = rl_f3(b.x, b.y, b.z);
+    r.q = b.w;
+    r.len = 0.0f;
+}
 
 // Open launches: per-workgroup LDS area behind the waves' scratch.
 struct RlOpenWg {
@@ -330,7 +351,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
     RlLdsU32* ring_b = (RlLdsU32*)ws->ring_b;
     RlLdsU32* ring_s = (RlLdsU32*)ws->ring_s;
-    uint32_t a_head = 0, a_tail = 0, b_head = 0, b_tail = 0, s_head = 0, s_tail = 0; // wave-uniform ring indices
+    // Wave-uniform ring indices: entries [lim - 64, tail) are waiting; a round runs when tail reaches lim (one compare per push).
+    uint32_t a_lim = 64u, a_tail = 0, b_lim = 64u, b_tail = 0, s_lim = 64u, s_tail = 0;
+    // A push writes slot ((tail + rank) & 127) of a ring: the wave's scratch is 512-byte aligned (rl_trace_body) and the rings are
+    // 512 bytes each, so the slot's LDS address is (scratch address | ((tail + rank) << 2 & 0x1fc)) + the ring's offset -- one
+    // v_add_lshl and one v_and_or behind the two v_mbcnt, the ring's offset in the store's immediate field.
+    const uint32_t ws_addr = (uint32_t)(size_t)(RlLdsU32*)ws;
+#define RL_RING_SLOT(RING, M, TAIL) \
+    ((RlLdsU32*)(size_t)((ws_addr | (((rl_mbcnt(M) + (TAIL)) << 2) & 0x1fcu)) + (uint32_t)offsetof(RlWaveScratch, RING)))
     const RlF4* sph = sv.spheres;
     // The scene's counts are launch constants.  Whatever is derived from them -- "is there any", "how many full groups of
     // four", the member loop's choice -- is loop-invariant over the kernel's persistent loop too, and the optimiser keeps
@@ -393,7 +421,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_STAT(RL_ST_B_LANES, count);
         RL_T0(t_b);
         rl_wave_sync();
-        const uint32_t e = ring_b[(b_head + lane) & 127u];
+        const uint32_t e = ring_b[(b_lim - 64u + lane) & 127u];
         const uint32_t owner = e & 63u;
         const uint32_t pos = e >> 6;
         // (the record depends on the ring entry alone: its loads are issued ahead of the cross-lane fetch, whose wait then
@@ -436,11 +464,11 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u) | (DISABLE_BIT)) >= 0;               \
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
         if (m != 0) {                                                                               \
-            if (cand) ring_b[rl_mbcnt_from(m, b_tail) & 127u] = ((POS) << 6) | (OWNER);               \
+            if (cand) *RL_RING_SLOT(ring_b, m, b_tail) = ((POS) << 6) | (OWNER);               \
             b_tail += (uint32_t)__popcll(m);                                                        \
-            if (RL_UNLIKELY(b_tail - b_head >= 64u)) {                                                           \
+            if (RL_UNLIKELY(b_tail >= b_lim)) {                                                           \
                 process_spheres(64u);                                                               \
-                b_head += 64u;                                                                      \
+                b_lim += 64u;                                                                      \
             }                                                                                       \
         }                                                                                           \
     }
@@ -471,10 +499,11 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     RL_T1(RL_ST_T_DIRECT, t_direct);
 
     RL_T0(t_cluster);
-    const RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
+    RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
     // Far bound of the cull: the nearest hit so far -- here the planes, circles and paraboloids (in the built-in scene
     // the floor, the walls and the ceiling: every ray has one), before the prisms also the spheres.
     float far = best.t * cr.len;
+    rl_store_cull_ray(ws, lane, cr, far); // (read by the rounds' lanes, behind their wave sync)
     // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members.  The members are
     // tested with the cull's own arithmetic -- on the device a clustered sphere's record is {centre, |c|^2 - R^2}, see
     // RlSceneView::sphere_r2 -- (8 FMAs, a v_med3 and a compare per member, far bound included) -- a conservative pre-test: ring B re-evaluates the pairs that pass with the
@@ -490,7 +519,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t n_members = cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
         const bool split = SPLIT && count <= 32u && (n_members == 10u || n_members == 14u);
         const uint32_t slot = split ? (lane & 31u) : lane;
-        const uint32_t e = ring_a[(a_head + slot) & 127u];
+        const uint32_t e = ring_a[(a_lim - 64u + slot) & 127u];
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
         uint32_t first = sv.cluster_base + (cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
@@ -499,7 +528,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (RL_W_M) mb = sph[first]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
         float r_far;
-        rl_fetch_cull_ray(owner, cr, far, r, r_far);
+        rl_fetch_cull_ray(ws, owner, r, r_far);
         if (!RL_W_M) mb = sph[first];
         // The members that pass are collected as one bit per member in a lane-private mask (one v_alignbit per member: shift
         // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
@@ -528,12 +557,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
             const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed | 0x80000000u); // (a lane with nothing left does not push; ctz(0) is undefined)
-            if (passed != 0u) ring_b[rl_mbcnt_from(any, b_tail) & 127u] = ((first + j) << 6) | owner;
+            if (passed != 0u) *RL_RING_SLOT(ring_b, any, b_tail) = ((first + j) << 6) | owner;
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;
-            if (RL_UNLIKELY(b_tail - b_head >= 64u)) {
+            if (RL_UNLIKELY(b_tail >= b_lim)) {
                 process_spheres(64u);
-                b_head += 64u;
+                b_lim += 64u;
             }
             any = __builtin_amdgcn_ballot_w64(passed != 0u);
         }
@@ -562,20 +591,20 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     }
     /* a child that passed: to ring A ... */                                                            \
 #define RL_PUSH_false(ENTRY, PROCESS_A)                                                                 \
-    if (pass) ring_a[rl_mbcnt_from(m, a_tail) & 127u] = (ENTRY);                                        \
+    if (pass) *RL_RING_SLOT(ring_a, m, a_tail) = (ENTRY);                                        \
     a_tail += (uint32_t)__popcll(m);                                                                    \
-    if (RL_UNLIKELY(a_tail - a_head >= 64u)) {                                                                       \
+    if (RL_UNLIKELY(a_tail >= a_lim)) {                                                                       \
         PROCESS_A(64u);                                                                                 \
-        a_head += 64u;                                                                                  \
+        a_lim += 64u;                                                                                  \
     }
     /* ... or, a prism of a scene whose prisms carry a second bound, to the cylinder round's ring (process_cylinders) */ \
 #define RL_PUSH_CYL(ENTRY, PROCESS_A)                                                                   \
     if (CYL) {                                                                                          \
-        if (pass) ring_b[rl_mbcnt_from(m, b_tail) & 127u] = (ENTRY);                                    \
+        if (pass) *RL_RING_SLOT(ring_b, m, b_tail) = (ENTRY);                                    \
         b_tail += (uint32_t)__popcll(m);                                                                \
-        if (RL_UNLIKELY(b_tail - b_head >= 64u)) {                                                                   \
+        if (RL_UNLIKELY(b_tail >= b_lim)) {                                                                   \
             process_cylinders(64u);                                                                     \
-            b_head += 64u;                                                                              \
+            b_lim += 64u;                                                                              \
         }                                                                                               \
     } else {                                                                                            \
         RL_PUSH_false(ENTRY, PROCESS_A)                                                                 \
@@ -590,7 +619,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_STAT(RL_ST_S_LANES, COUNT);                                                                  \
         RL_T0(t_s);                                                                                     \
         rl_wave_sync();                                                                                 \
-        const uint32_t e = ring_s[(s_head + lane) & 127u];                                              \
+        const uint32_t e = ring_s[(s_lim - 64u + lane) & 127u];                                              \
         const uint32_t owner = e & 63u;                                                                 \
         const uint32_t first = (ITEM_BASE) + (G) * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
         /* (UNROLL_S: the children's bounds depend on the ring entry alone and are requested ahead of the cross-lane fetch, \
@@ -602,7 +631,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }                                                                                               \
         RlCullRay r;                                                                                    \
         float r_far;                                                                                    \
-        rl_fetch_cull_ray(owner, cr, far, r, r_far);                                                    \
+        rl_fetch_cull_ray(ws, owner, r, r_far);                                                    \
         if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
         if (UNROLL_S) {                                                                                 \
             _Pragma("unroll") for (uint32_t j = 0; j < 4u; ++j) {                                       \
@@ -629,26 +658,26 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
             g0 = gb[g + 1];                                                                             \
             if (m != 0) {                                                                               \
-                if (pass) ring_s[rl_mbcnt_from(m, s_tail) & 127u] = (g << 6) | lane; /* group number within its kind */ \
+                if (pass) *RL_RING_SLOT(ring_s, m, s_tail) = (g << 6) | lane; /* group number within its kind */ \
                 s_tail += (uint32_t)__popcll(m);                                                        \
-                if (RL_UNLIKELY(s_tail - s_head >= 64u)) {                                                           \
+                if (RL_UNLIKELY(s_tail >= s_lim)) {                                                           \
                     RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                   \
-                    s_head += 64u;                                                                      \
+                    s_lim += 64u;                                                                      \
                 }                                                                                       \
             }                                                                                           \
         }                                                                                               \
-        if (s_tail != s_head) {                                                                         \
-            const uint32_t left = s_tail - s_head;                                                      \
+        if (s_tail != s_lim - 64u) {                                                                    \
+            const uint32_t left = s_tail - (s_lim - 64u);                                               \
             RL_GROUP_ROUND(left, G, ITEM_BASE, PROCESS_A, CYL)                                          \
-            s_head = s_tail;                                                                            \
+            s_lim = s_tail + 64u;                                                                       \
         }                                                                                               \
     }
     // ---- sphere clusters: group culls -> ring S -> cluster bounds -> ring A -> members -> ring B ----
     if (n_cluster_groups != 0) {
         RL_GROUP_CULLS(0u, n_cluster_groups, group_gc, 0u, process_clusters, false)
         RL_STAT(RL_ST_S_ITEMS, s_tail);
-        if (a_tail != a_head) process_clusters(a_tail - a_head);
-        a_head = a_tail;
+        if (a_tail != a_lim - 64u) process_clusters(a_tail - (a_lim - 64u));
+        a_lim = a_tail + 64u;
         RL_STAT(RL_ST_A_ITEMS, a_tail);
     }
 #ifdef RL_STATS
@@ -657,11 +686,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_SPHERE_REJECT
     RL_T1(RL_ST_T_CLUSTER, t_cluster);
     RL_T0(t_tail);
-    if (b_tail != b_head) process_spheres(b_tail - b_head);
-    b_head = b_tail;
+    if (b_tail != b_lim - 64u) process_spheres(b_tail - (b_lim - 64u));
+    b_lim = b_tail + 64u;
     RL_T1(RL_ST_T_TAIL, t_tail);
     RL_T0(t_prism);
     far = rl_u2f((uint32_t)(keys[lane] >> 32)) * cr.len; // every sphere has been merged by now (process_spheres ends in a wave sync)
+    ((RlLdsF*)&ws->far[0])[lane] = far;
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
     auto process_prisms = [&](uint32_t count) {
@@ -669,8 +699,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         RL_STAT(RL_ST_P_LANES, count);
         RL_T0(t_p);
         rl_wave_sync();
-        const uint32_t e = ring_a[(a_head + lane) & 127u];
-        const uint32_t owner = e & 63u;
+        uint32_t e = ring_a[(a_lim - 64u + lane) & 127u];
+        uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
         RlF3 ro, rd;
         rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
@@ -679,12 +709,26 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // wave-uniform, and with the same result for the lanes the shortcut had decided.
         const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * (lane < count ? prism : 0u);
         RlCand c;
-        int status = rl_hex_prism_fast(pr, ro, rd, &c);
+        int status = rl_hex_prism_fast<HOIST_S>(pr, ro, rd, &c); // (HOIST_S: the plain launches of a scene staged in LDS)
         if (lane >= count) status = RL_PRISM_MISS;
         if (__builtin_amdgcn_ballot_w64(status == RL_PRISM_UNSURE) != 0) {
             RL_STAT(RL_ST_P_SLOW, 1);
             c = rl_hex_prism(pr, ro, rd);
             status = (lane < count && c.t >= 0.0f) ? RL_PRISM_HIT : RL_PRISM_MISS;
+            // (the tree holds 8 normals, 8 offsets and 8 distances at once and sets the kernel's register count: this lane's own
+            // cull terms are read back from the wave's scratch behind it instead of being held across it ...)
+            {
+                asm volatile("" ::: "memory");
+                const float keep_len = cr.len;
+                rl_fetch_cull_ray(ws, lane, cr, far);
+                cr.len = keep_len;
+            }
+            // (... and so is the pair's ring entry)
+            uint32_t again = a_lim - 64u; // (opaque: computed here, not carried across the tree either)
+            asm volatile("" : "+s"(again) : : "memory");
+            e = ring_a[(again + lane) & 127u];
+            owner = e & 63u;
+            pr = sv.prisms + RL_PRISM_STRIDE * (lane < count ? (e >> 6) : 0u);
         }
         if (status == RL_PRISM_HIT) {
             const uint32_t obj = rl_f2u(pr[1].w);
@@ -700,20 +744,21 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // instructions for each of a group's three children whatever the sphere said): glass scene +0.7 %.
     auto process_cylinders = [&](uint32_t count) {
         rl_wave_sync();
-        const uint32_t e = ring_b[(b_head + lane) & 127u];
+        const uint32_t e = ring_b[(b_lim - 64u + lane) & 127u];
         const uint32_t owner = e & 63u;
         const RlF4* cy = prism_cyl + 2u * (lane < count ? (e >> 6) : 0u);
         const RlF4 cy0 = cy[0], cy1 = cy[1]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
-        rl_fetch6(owner, cr.d.x, cr.d.y, cr.d.z, cr.m.x, cr.m.y, cr.m.z, r.d.x, r.d.y, r.d.z, r.m.x, r.m.y, r.m.z);
+        float r_far_unused;
+        rl_fetch_cull_ray(ws, owner, r, r_far_unused);
         const bool pass = lane < count && rl_cyl_pass(r, cy0, rl_xyz(cy1));
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
-            if (pass) ring_a[rl_mbcnt_from(m, a_tail) & 127u] = e;
+            if (pass) *RL_RING_SLOT(ring_a, m, a_tail) = e;
             a_tail += (uint32_t)__popcll(m);
-            if (RL_UNLIKELY(a_tail - a_head >= 64u)) {
+            if (RL_UNLIKELY(a_tail >= a_lim)) {
                 process_prisms(64u);
-                a_head += 64u;
+                a_lim += 64u;
             }
         }
         rl_wave_sync();
@@ -727,11 +772,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_GROUP_CHILD_OF
 #undef RL_PUSH_CYL
 #undef RL_PUSH_false
-    if (CYL && b_tail != b_head) {
-        process_cylinders(b_tail - b_head);
-        b_head = b_tail;
+#undef RL_RING_SLOT
+    if (CYL && b_tail != b_lim - 64u) {
+        process_cylinders(b_tail - (b_lim - 64u));
+        b_lim = b_tail + 64u;
     }
-    if (a_tail != a_head) process_prisms(a_tail - a_head);
+    if (a_tail != a_lim - 64u) process_prisms(a_tail - (a_lim - 64u));
     RL_T1(RL_ST_T_PRISM, t_prism);
 #ifdef RL_STATS
     {
@@ -777,13 +823,13 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         for (uint32_t i = threadIdx.x; i < lay.total_f4; i += RL_TRACE_BLOCK) smem[i] = scene[i];
         __syncthreads();
         base = big = smem;
-        scratch = (RlWaveScratch*)(smem + lay.total_f4);
+        scratch = (RlWaveScratch*)(smem + ((lay.total_f4 + 31u) & ~31u)); // 512-byte aligned (rl_scan_wave's ring addressing; stage_of() rounds up likewise)
     } else if (STAGE == RL_STAGE_TABLES) {
         const uint32_t n_staged = lay.off_objects - lay.off_planes;
         for (uint32_t i = threadIdx.x; i < n_staged; i += RL_TRACE_BLOCK) smem[i] = scene[lay.off_planes + i];
         __syncthreads();
         base = smem;
-        scratch = (RlWaveScratch*)(smem + n_staged);
+        scratch = (RlWaveScratch*)(smem + ((n_staged + 31u) & ~31u));
     }
     const uint32_t tab0 = STAGE == RL_STAGE_TABLES ? lay.off_planes : 0u; // blob offset of `base`'s first record
 
@@ -810,10 +856,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
     typedef __attribute__((address_space(3))) float RlLdsF32;
     RlLdsF32* stash = (RlLdsF32*)&ws->stash[0][0];
-    RlLdsU32* stash_off = (RlLdsU32*)&ws->stash_off[0][0];
 
     uint64_t chunk_next = 0, chunk_end = 0;     // wave-uniform: this wave's slice of the global queue
     uint32_t stash_head = 0, stash_count = 0;   // wave-uniform
+    uint64_t stash_path0 = 0;                   // wave-uniform: slot s of the stash holds path stash_path0 + s of the RNG stream ...
+    uint32_t stash_valid = 0;                   // ... if s < stash_valid (the tail of a launch / call: fewer than 64 paths left)
     bool drained = false;                       // wave-uniform: the queue has no more paths for this wave
     bool active = false;
     uint64_t my_path = 0;  // the path's index in its RNG stream
@@ -840,7 +887,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     uint32_t known_local = 0;          // wave-uniform: jobs known to this wave
     bool pend_me = false;              // this lane's path finished in the last iteration (my_job is still its job)
     bool pend_any = false;             // wave-uniform: some lane's did
-    uint32_t emit_pend = 0, emit_pend_base = 0; // wave-uniform: the emitter batch splatted in the last iteration
+    uint32_t emit_pend = 0; // wave-uniform: the size of the emitter batch splatted in the last iteration (its calls: ring B)
     RlOpenWg* wgp = (RlOpenWg*)(scratch + RL_TRACE_BLOCK / 64);
     RlLdsU32* wg_fin = (RlLdsU32*)&wgp->fin[0];
     RlLdsU32* wg_seg = (RlLdsU32*)&wgp->seg[0];
@@ -862,7 +909,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (pend_me) __hip_atomic_fetch_add(wg_fin + my_job, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (lane < emit_pend)
-            __hip_atomic_fetch_add(wg_fin + (rl_f2u(emit[4 * 128 + ((emit_pend_base + lane) & 127u)]) >> 24), 1u, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(wg_fin + (((RlLdsU32*)ws->ring_b)[lane] >> 24), 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         pend_me = false;
         pend_any = false;
@@ -914,14 +961,18 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     auto process_emitted = [&](uint32_t count) {
         RL_STAT(RL_ST_EMIT_BATCHES, 1);
         RL_STAT(RL_ST_EMIT_LANES, count);
+        if (OPEN && emit_pend != 0) settle(); // (a second batch in one iteration -- 64 paths ending at once: count the first before its tags go)
         rl_wave_sync();
         if (lane < count) {
-            const uint32_t slot = (e_head + lane) & 127u;
-            const float sx = emit[0 * 128 + slot], sy = emit[1 * 128 + slot], wavelength = emit[2 * 128 + slot];
-            const uint32_t tagged = rl_f2u(emit[4 * 128 + slot]);
+            const uint32_t slot = (e_head + lane) & 63u;
+            const float sx = emit[0 * 64 + slot], sy = emit[1 * 64 + slot], wavelength = emit[2 * 64 + slot];
+            const uint32_t tagged = rl_f2u(emit[4 * 64 + slot]);
+            // (OPEN: settle() counts these paths per call an iteration from now, when the queue's slots may hold newer entries:
+            // the tags wait in ring B, which is empty between two scans)
+            if (OPEN) ((RlLdsU32*)ws->ring_b)[lane] = tagged;
             float* target = plot;
             if (OPEN) target = (float*)jobs[tagged >> 24].target;
-            const float value = rl_emission(sv, emit[3 * 128 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
+            const float value = rl_emission(sv, emit[3 * 64 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
                 uint32_t width = job.width, height = job.height; // opaque: `width - 1` etc. are re-derived here instead of living in
@@ -936,10 +987,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 }
             }
         }
-        if (OPEN) { // these paths are finished once the adds above are acknowledged: settle() counts them
-            emit_pend = count;
-            emit_pend_base = e_head;
-        }
+        if (OPEN) emit_pend = count; // these paths are finished once the adds above are acknowledged: settle() counts them
         rl_wave_sync();
     };
 
@@ -978,19 +1026,6 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             asm volatile("s_cmp_eq_u32 0, 1");
 #pragma unroll
             for (int k = 0; k < 64; ++k) asm volatile("s_cbranch_scc1 0");
-#elif RL_EXP_EXTRA == 10 // 4 batches of nine cross-lane fetches with one wait each
-            {
-                float t0 = (float)lane;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    RlCullRay in, out;
-                    in.d = rl_f3(t0, t0 + 1.0f, t0 + 2.0f); in.m = rl_f3(t0 + 3.0f, t0 + 4.0f, t0 + 5.0f); in.p = t0 + 6.0f; in.q = t0 + 7.0f; in.len = 0.0f;
-                    float of;
-                    rl_fetch_cull_ray((lane * 7u + 3u) & 63u, in, t0 + 8.0f, out, of);
-                    t0 = out.d.x + out.d.y + out.d.z + out.m.x + out.m.y + out.m.z + out.p + out.q + of;
-                }
-                xv = rl_f2u(t0);
-            }
 #elif RL_EXP_EXTRA == 11 // 64 s_and_saveexec / s_or exec pairs
 #pragma unroll
             for (int k = 0; k < 64; ++k) asm volatile("s_and_saveexec_b64 s[2:3], exec\n\ts_or_b64 exec, exec, s[2:3]" ::: "s2", "s3");
@@ -1147,10 +1182,12 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 }
                 RL_STAT(RL_ST_REFILLS, 1);
                 if (OPEN) stash_first = jobs[stash_job].first_path;
-                const uint64_t offset = chunk_next + lane;
+                const uint64_t limit = OPEN ? (uint64_t)open_n : job.n_paths;
+                stash_path0 = stash_first + chunk_next;
+                stash_valid = chunk_next >= limit ? 0u : (limit - chunk_next >= 64ull ? 64u : (uint32_t)(limit - chunk_next));
                 chunk_next += 64;
-                const bool valid = offset < (OPEN ? (uint64_t)open_n : job.n_paths);
-                const uint64_t path_index = stash_first + offset;
+                const bool valid = lane < stash_valid;
+                const uint64_t path_index = stash_path0 + lane;
                 RlPath fresh = p;
                 RL_T0(t_cam);
                 if (valid) rl_begin_path(sv, job.aspect_ratio, job.seed, job.stream, path_index, &fresh);
@@ -1166,8 +1203,6 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 stash[7 * 64 + lane] = fresh.sx;
                 stash[8 * 64 + lane] = fresh.sy;
                 stash[9 * 64 + lane] = fresh.ior;
-                stash_off[lane] = valid ? (uint32_t)path_index : 0xffffffffu;       // (~0, ~0) marks "no path"; a real
-                stash_off[64 + lane] = valid ? (uint32_t)(path_index >> 32) : 0xffffffffu; // index never gets there
                 rl_wave_sync();
                 stash_head = 0;
                 stash_count = 64;
@@ -1177,9 +1212,8 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             const uint32_t rank = rl_mbcnt(need);
             if (!active && rank < avail) {
                 const uint32_t slot = stash_head + rank;
-                const uint32_t lo = stash_off[slot], hi = stash_off[64 + slot];
-                if ((lo & hi) != 0xffffffffu) {
-                    my_path = ((uint64_t)hi << 32) | lo;
+                if (slot < stash_valid) {
+                    my_path = stash_path0 + slot;
                     if (OPEN) my_job = stash_job;
                     p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
                     p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
@@ -1213,11 +1247,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         }
         // (ring-S rounds unrolled wherever the cull table is in LDS -- except in the fused open launches of a tables-only scene, the
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), !OPEN && RL_W_S>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(FUSED && OPEN) && RL_W_S>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
-            const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? (rl_f2u(sv.objects[2 * hit.obj].x) >> 8) : 99u;
+            const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? rl_object_material(rl_f2u(sv.objects[hit.obj].w)) : 99u;
             const uint64_t m_act = __builtin_amdgcn_ballot_w64(active);
             const uint64_t m_void = __builtin_amdgcn_ballot_w64(active && hit.obj == RL_HIT_NONE);
             const uint64_t m_emit = __builtin_amdgcn_ballot_w64(mk == RL_MATERIAL_BLACK_BODY);
@@ -1290,17 +1324,24 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             // ---- fused splat (plot_unit.rs:56-95), deferred: queue the paths that ended on a light ----
             const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
             if (m != 0) {
+                // The queue holds 64 paths.  A batch runs when it is exactly full -- or, before these paths would overflow it,
+                // with the (nearly 64) it has: ~2 paths end on a light per iteration, so batches are ~97 % full.
+                const uint32_t n_new = (uint32_t)__popcll(m);
+                if (RL_UNLIKELY(e_tail - e_head + n_new > 64u)) {
+                    process_emitted(e_tail - e_head);
+                    e_head = e_tail;
+                }
                 if (ended_on_emitter) {
-                    const uint32_t slot = rl_mbcnt_from(m, e_tail) & 127u;
-                    emit[0 * 128 + slot] = p.sx;
-                    emit[1 * 128 + slot] = p.sy;
-                    emit[2 * 128 + slot] = p.wavelength;
-                    emit[3 * 128 + slot] = p.intensity;
-                    emit[4 * 128 + slot] = rl_u2f(emit_obj);
+                    const uint32_t slot = rl_mbcnt_from(m, e_tail) & 63u;
+                    emit[0 * 64 + slot] = p.sx;
+                    emit[1 * 64 + slot] = p.sy;
+                    emit[2 * 64 + slot] = p.wavelength;
+                    emit[3 * 64 + slot] = p.intensity;
+                    emit[4 * 64 + slot] = rl_u2f(emit_obj);
                     ended_on_emitter = false;
                 }
-                e_tail += (uint32_t)__popcll(m);
-                if (RL_UNLIKELY(e_tail - e_head >= 64u)) {
+                e_tail += n_new;
+                if (RL_UNLIKELY(e_tail - e_head == 64u)) {
                     process_emitted(64u);
                     e_head += 64u;
                 }

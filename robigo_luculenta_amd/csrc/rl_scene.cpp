@@ -699,7 +699,7 @@ std::vector<RlF4> sample_path_rays(const RlFlatScene& fs, const std::vector<Sphe
     std::vector<RlF4> spheres, objects = fs.objects;
     std::vector<uint32_t> sphere_obj;
     for (const SphereIn& si : sph) {
-        objects[2 * si.obj].y = rl_u2f((uint32_t)spheres.size());
+        objects[si.obj].w = rl_u2f(rl_object_bits(rl_object_surface(rl_f2u(objects[si.obj].w)), rl_object_material(rl_f2u(objects[si.obj].w)), (uint32_t)spheres.size()));
         spheres.push_back(si.rec);
         sphere_obj.push_back(si.obj);
     }
@@ -715,7 +715,7 @@ std::vector<RlF4> sample_path_rays(const RlFlatScene& fs, const std::vector<Sphe
     sv.n_planes = (uint32_t)(fs.planes.size() / 2);
     sv.n_parabs = (uint32_t)(fs.parabs.size() / 3);
     sv.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
-    sv.n_objects = (uint32_t)(objects.size() / 2);
+    sv.n_objects = (uint32_t)objects.size();
     sv.camera_rec = fs.camera_rec.data();
     RlSceneView flat_things = sv; // planes, circles, paraboloids only
     flat_things.n_direct = 0;
@@ -785,6 +785,11 @@ uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, 
     if (camera) *camera = demo_camera();
     if (out) *out = objs;
     return (uint32_t)objs.size();
+}
+
+static void set_group(RlF4& object, uint32_t group_index) {
+    const uint32_t bits = rl_f2u(object.w);
+    object.w = rl_u2f(rl_object_bits(rl_object_surface(bits), rl_object_material(bits), group_index));
 }
 
 int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err) {
@@ -861,17 +866,14 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
             *err = "unknown surface kind";
             return RL_E_INVALID;
         }
-        RlF4 a, b;
-        a.x = rl_u2f((o.surface_kind & 0xffu) | (o.material_kind << 8));
-        a.y = rl_u2f(group_index);
-        a.z = 0.0f; a.w = 0.0f;
-        b.x = o.m0; b.y = o.m1; b.z = o.m2; b.w = 0.0f;
+        RlF4 b;
+        b.x = o.m0; b.y = o.m1; b.z = o.m2;
+        b.w = rl_u2f(rl_object_bits(o.surface_kind, o.material_kind, group_index));
         if (o.material_kind == RL_MATERIAL_BLACK_BODY) b.y = rl_black_body_normalisation(o.m0, o.m1);
         else if (o.material_kind > RL_MATERIAL_SOAP_BUBBLE) {
             *err = "unknown material kind";
             return RL_E_INVALID;
         }
-        fs.objects.push_back(a);
         fs.objects.push_back(b);
     }
     // ---- spheres: direct list + clusters ----
@@ -910,7 +912,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         const uint32_t pos = (uint32_t)fs.spheres.size();
         fs.spheres.push_back(sph_in[k].rec);
         fs.sphere_obj.push_back(sph_in[k].obj);
-        fs.objects[2 * sph_in[k].obj].y = rl_u2f(pos); // group index = record position
+        set_group(fs.objects[sph_in[k].obj], pos); // group index = record position
     };
     for (uint32_t k : direct) place(k);
     fs.n_direct = (uint32_t)direct.size();
@@ -980,7 +982,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         for (const std::vector<uint32_t>& g : groups) {
             for (uint32_t k : g) {
                 const RlF4* pr = &fs.prisms[RL_PRISM_STRIDE * k];
-                fs.objects[2 * rl_f2u(pr[1].w)].y = rl_u2f((uint32_t)(sorted.size() / RL_PRISM_STRIDE)); // group index = position
+                set_group(fs.objects[rl_f2u(pr[1].w)], (uint32_t)(sorted.size() / RL_PRISM_STRIDE)); // group index = position
                 sorted.insert(sorted.end(), pr, pr + RL_PRISM_STRIDE);
             }
             for (size_t pad = g.size(); pad < RL_GROUP_GP; ++pad) {

@@ -17,8 +17,9 @@
 //                             + {bounding-sphere centre.xyz, radius^2} (not in the reference: a
 //                             conservative cull, see rl_bound_pass); the odd stride also keeps
 //                             per-lane prism fetches off a single LDS bank row
-//   objects   2 x RlF4 each : {surface_kind | material_kind << 8, group index, 0, 0} as bits,
-//                             {m0, m1, m2, 0}  (black body: m0 = kelvins, m1 = normalisation factor)
+//   objects   1 x RlF4 each : {m0, m1, m2, bits: surface_kind | material_kind << 3 | group index << 6}
+//                             (black body: m0 = kelvins, m1 = normalisation factor; one 16-byte record per object since round 5 --
+//                             the table is read once per bounce and is a third of what a scene stages in LDS)
 //
 // The direct sphere list is padded with never-hit dummies (radius^2 = -inf) to a multiple of 4 plus
 // one extra group of 4, so the kernel can unroll by 4 and prefetch one group ahead without a bounds
@@ -116,3 +117,11 @@ uint32_t rl_builtin_scene(int which, int param, std::vector<RlObjectDesc>* out, 
 
 RL_HD uint32_t rl_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 RL_HD float rl_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// The fourth component of an object record: what it is and where its primitive's records are (the sphere's position in
+// `spheres`, the plane's / paraboloid's / prism's number in its list).
+RL_HD uint32_t rl_object_bits(uint32_t surface_kind, uint32_t material_kind, uint32_t group_index) {
+    return (surface_kind & 7u) | ((material_kind & 7u) << 3) | (group_index << 6);
+}
+RL_HD uint32_t rl_object_surface(uint32_t bits) { return bits & 7u; }
+RL_HD uint32_t rl_object_material(uint32_t bits) { return (bits >> 3) & 7u; }
+RL_HD uint32_t rl_object_group(uint32_t bits) { return bits >> 6; }

@@ -44,7 +44,7 @@ void* mirror_scene_create(const RlObjectDesc* objs, uint32_t n, const RlCameraDe
     v.n_planes = (uint32_t)(m->flat.planes.size() / 2);
     v.n_parabs = (uint32_t)(m->flat.parabs.size() / 3);
     v.n_prisms = (uint32_t)(m->flat.prisms.size() / RL_PRISM_STRIDE);
-    v.n_objects = (uint32_t)(m->flat.objects.size() / 2);
+    v.n_objects = (uint32_t)m->flat.objects.size();
     v.camera_rec = m->flat.camera_rec.data();
     return m;
 }
