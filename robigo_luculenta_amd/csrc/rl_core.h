@@ -86,8 +86,8 @@ RL_HD RlF3 rl_normalise(RlF3 v) {                                               
     const uint32_t bx = rl_f2u(v.x) & 0x7fffffffu, by = rl_f2u(v.y) & 0x7fffffffu, bz = rl_f2u(v.z) & 0x7fffffffu;
     uint32_t least = bx - 1u < by - 1u ? bx - 1u : by - 1u; // (0 - 1 wraps to the largest value: zeros pass)
     least = bz - 1u < least ? bz - 1u : least;
-    const bool plain = least >= 0x1f800000u - 1u                         // every component is 0 or at least 2^-64
-                       && rl_f2u(d2) - 0x0f800000u < 0x7a800000u - 0x0f800000u; // 2^-96 <= |v|^2 < 2^118: 2^-48 <= m < 2^59 (NaN and 0 fail)
+    const bool plain = (least >= 0x1f800000u - 1u)                       // every component is 0 or at least 2^-64
+                       & (rl_f2u(d2) - 0x0f800000u < 0x7a800000u - 0x0f800000u); // 2^-96 <= |v|^2 < 2^118: 2^-48 <= m < 2^59 (NaN and 0 fail)
     if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) {
         const float ys = __builtin_amdgcn_rsqf(d2);
         const float s = d2 * ys, h = 0.5f * ys;
@@ -304,8 +304,17 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     const float sq = rl_sqrtf(disc, true); // (a negative discriminant is a miss whatever `sq` is)
     const float np = -b + sq, nq = -b - sq;
     const float pick = np < 0.0f ? np : nq;
-    const bool plain = a < 0.0f && (disc < 0.0f || ((fabsf(np) >= 1.0e-37f || np == 0.0f) && (fabsf(nq) >= 1.0e-37f || nq == 0.0f)));
-    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) return (disc < 0.0f || !(pick < 0.0f)) ? -1.0f : 0.5f * pick / a;
+    // (one unsigned compare per numerator: |n| >= 2^-123 or n == 0 -- the zero wraps round; an exact zero is common, a ray that
+    // leaves the paraboloid has c ~ 1e-5 and its discriminant rounds to b^2.  A NaN passes as well and gives the literal form's
+    // "no hit" here too: every comparison with it is false in both.  The conditions are combined with | and &, not || and &&:
+    // as written with those the compiler built a tree of a dozen exec-mask branches around eight compares, ~45 scalar
+    // instructions per paraboloid, and a wave's time goes into issuing instructions whatever their kind)
+    const uint32_t up = (rl_f2u(np) & 0x7fffffffu) - 1u, uq = (rl_f2u(nq) & 0x7fffffffu) - 1u;
+    const bool plain = (a < 0.0f) & ((disc < 0.0f) | ((up >= 0x02000000u - 1u) & (uq >= 0x02000000u - 1u)));
+    if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) {
+        const float t = 0.5f * pick / a; // (for every lane: the quotient of a miss is discarded -- no branch around the division)
+        return ((disc < 0.0f) | !(pick < 0.0f)) ? -1.0f : t;
+    }
 #endif
     return rl_paraboloid_roots(a, b, c);
 }
@@ -485,7 +494,7 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
     const float scale = U64 * pr[2].w;
     const float s0 = fabsf(o.x) + fabsf(o.y) + fabsf(o.z) + pr[0].w;
     // not decided here: a ray nearly parallel to a face, a crossing at the origin (NaNs fail both compares)
-    bool sure = min_dn >= 1.52587890625e-05f * pr[2].w * d1 && min_ta >= 1.0e-30f;
+    bool sure = (min_dn >= 1.52587890625e-05f * pr[2].w * d1) & (min_ta >= 1.0e-30f); // (& and | below: no branches, see rl_paraboloid_t)
     const uint32_t k_e = rl_f2u(t_in) & 7u, k_x = rl_f2u(t_out) & 7u;
     const float dn_e = rl_dot(rl_xyz(pr[2 * k_e]), d), dn_x = rl_dot(rl_xyz(pr[2 * k_x]), d); // = dn[k_e], dn[k_x]
     const bool from_outside = t_in > 0.0f;
@@ -509,8 +518,8 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
     const float t_first = (min_pos & 0x80000000u) ? INF : rl_u2f(min_pos);
     const float miss_a = gap * fminf(fabsf(dn_e), dn_x), delta_a = 2.0f * scale * (s0 + d1 * fmaxf(t0, fabsf(t_out)));
     const float miss_b = dn_x * (t_first - t_out), delta_b = scale * (s0 + d1 * t_first);
-    const bool miss_sure = from_outside ? miss_a > delta_a : (!(t_first < INF) || miss_b > delta_b);
-    sure = sure && (reaches ? hit_sure : miss_sure);
+    const bool miss_sure = from_outside ? miss_a > delta_a : (!(t_first < INF) | (miss_b > delta_b));
+    sure = sure & (reaches ? hit_sure : miss_sure);
     // the reference's own t for plane k* (geometry.rs:62)
     const RlF3 n = rl_xyz(pr[2 * k_star]);
     const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k_star + 1]));
@@ -690,7 +699,7 @@ RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) 
 #if defined(__HIP_DEVICE_COMPILE__)
     const float e_fast = __builtin_amdgcn_exp2f(intensity * -28.853901f); // -20 log2(e)
     const float gap = unit * 0.85f - continue_chance * (1.0f - e_fast);
-    const bool undecided = !(fabsf(gap) >= 2.0e-5f) || !(intensity >= 0.0f && intensity <= 1.0f);
+    const bool undecided = !(fabsf(gap) >= 2.0e-5f) | !((intensity >= 0.0f) & (intensity <= 1.0f));
     if (RL_LIKELY(__builtin_amdgcn_ballot_w64(undecided) == 0)) return gap > 0.0f;
 #endif
     return unit * 0.85f > continue_chance * (1.0f - rl_expf(intensity * -20.0f));
@@ -701,50 +710,8 @@ RL_HD bool rl_roulette_ends(float unit, float continue_chance, float intensity) 
 // RL_PATH_ENDED_ON_EMITTER: the path hit emitter *emitter; its contribution is
 // rl_emission(sv, p->intensity, p->wavelength, *emitter), left to the caller so that the kernel can
 // evaluate the f64 Planck term for 64 ended paths at once instead of under divergence.
-// rl_acosf(a0), rl_acosf(a1) for the lanes with `wanted`.  On the GPU: called by every lane of a branch (whatever set of
-// lanes that is); the 2n arguments of the n wanting lanes are handed, through 128 floats of per-wave LDS scratch, to the
-// first 2n lanes of the branch, evaluated in one pass and handed back.  More arguments than lanes: one pass each.
-RL_HD void rl_acos_pair(bool wanted, float a0, float a1, float* scratch, float* r0, float* r1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // The device fast paths of this header (here, rl_normalise, rl_paraboloid_t, rl_roulette_ends) are written for a 64-wide
-    // wave: 64-bit ballots, 128 floats of scratch = two slots per lane.  `scratch` must be per-wave memory that nothing else
-    // uses while the caller's branch runs -- the trace kernel passes ring B, which is empty between two scans.
-    // (a build for another target stops at the #error at the head of this file)
-    typedef __attribute__((address_space(3))) float LdsF32;
-    LdsF32* slots = (LdsF32*)scratch;
-    const uint64_t here = __builtin_amdgcn_ballot_w64(true), want = __builtin_amdgcn_ballot_w64(wanted);
-    const uint32_t n = (uint32_t)__popcll(want);
-    *r0 = *r1 = 0.0f;
-    if (n == 0) return;
-    if (2u * n <= (uint32_t)__popcll(here)) {
-        const uint32_t mine = __builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u));
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
-        if (wanted) {
-            slots[rank] = a0;
-            slots[n + rank] = a1;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const float r = rl_acosf(mine < 2u * n ? slots[mine] : 0.0f);
-        if (mine < 2u * n) slots[64 + mine] = r;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (wanted) {
-            *r0 = slots[64 + rank];
-            *r1 = slots[64 + n + rank];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return;
-    }
-#endif
-    *r0 = wanted ? rl_acosf(a0) : 0.0f;
-    *r1 = wanted ? rl_acosf(a1) : 0.0f;
-}
-
-// pair_scratch: 128 floats of per-wave LDS that nothing else uses during the bounce (GPU); unused on the host.
 RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint64_t path_index, RlPath* p,
-                    const RlHit& hit, float* value, uint32_t* emitter, float* pair_scratch = nullptr) {
+                    const RlHit& hit, float* value, uint32_t* emitter) {
     *value = 0.0f;
     if (hit.obj == RL_HIT_NONE) return RL_PATH_ENDED; // The Void
     const RlF4 ob = sv.objects[hit.obj];
@@ -809,11 +776,15 @@ RL_HD int rl_bounce(const RlSceneView& sv, uint64_t seed, uint32_t stream, uint6
             cos_phi = rl_clamp999(rl_dot(new_dir, is.normal));
             cos_theta = rl_clamp999(rl_dot(new_dir, unit_axis)); // Intersection.tangent
         }
-        // The film's two arc cosines (material.rs:293-294): ~17 % of a wave's lanes need them, two each, at ~55 instructions
-        // of f64 arithmetic apiece -- the GPU evaluates both arguments of every film lane in ONE pass over the lanes that
-        // are enabled here (rl_acos_pair: everything that is not glass), the same function of the same arguments.
-        float acos_phi, acos_theta;
-        rl_acos_pair(soap, cos_phi, cos_theta, pair_scratch, &acos_phi, &acos_theta);
+        // The film's two arc cosines (material.rs:293-294), under the film lanes' mask.  (Rounds 3-4 packed the 2n arguments of
+        // the n film lanes into the first 2n lanes of the branch through LDS and evaluated them in one pass: better lane use,
+        // but ~25 instructions and three LDS round trips more than the second evaluation costs -- and a wave's time goes into
+        // issuing instructions, DESIGN.md 4.2: +0.3 % without it.)
+        float acos_phi = 0.0f, acos_theta = 0.0f;
+        if (soap) {
+            acos_phi = rl_acosf(cos_phi);
+            acos_theta = rl_acosf(cos_theta);
+        }
         if (soap) {
             const float phase_shift = rl_div200f(p->wavelength - 380.0f) * RL_PI_F;
             angle = phase_shift - acos_phi * 3.0f - acos_theta * 2.0f + RL_PI_F * 0.5f;

@@ -273,13 +273,14 @@ struct RlWaveScratch {
     uint32_t ring_a[128];       // (cluster or prism index << 6) | owner lane
     uint32_t ring_b[128];       // (sphere record position << 6) | owner lane
     uint32_t ring_s[128];       // (group index << 6) | owner lane: second level of the cull table
-    // The cull terms of the wave's 64 rays, one 32-byte slot per lane: {d.xyz, p}, {m.xyz, q} (RlCullRay), and the far bounds.
+    // The cull terms of the wave's 64 rays, two 16-byte slots per lane: {d.xyz, p}, {m.xyz, q} (RlCullRay), and the far bounds.
     // Written by every lane once per scan; a round's lane reads the slot of its pair's OWNER with two 16-byte loads and one
     // 4-byte load.  Rounds 1-4 fetched the nine values across lanes with nine ds_bpermute_b32 -- ~430 cycles of a wave's
     // time per round measured in the kernel (tools/ab3.sh, the RL_EXP_EXTRA probes), against ~90 for the gathers; five such
     // rounds per iteration.  The room came from the emitter queue (128 -> 64 slots), the stash's path indices (derived
     // now) and the object table (one record per object).
-    float terms[64][8];
+    float terms_d[64][4]; // {d.xyz, p}: two arrays of 16-byte slots rather than one of 32-byte ones -- a 16-byte gather is served
+    float terms_m[64][4]; // {m.xyz, q}  in groups of 16 lanes, and 16-byte strides spread 16 owners over all 16 bank quads
     float far[64];
     // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior.  Refilled with all 64 lanes
     // busy; slot s holds path (stash_path0 + s) of the RNG stream, the first stash_valid slots hold a path at all
@@ -296,21 +297,27 @@ typedef __attribute__((address_space(3))) RlV4 RlLdsV4;
 typedef __attribute__((address_space(3))) float RlLdsF;
 // A lane's cull terms (and far bound) into its slot of the wave's scratch, once per scan ...
 __device__ __forceinline__ void rl_store_cull_ray(RlWaveScratch* ws, uint32_t lane, const RlCullRay& cr, float far) {
-    RlLdsV4* slots = (RlLdsV4*)&ws->terms[0][0];
-    slots[2u * lane] = (RlV4){cr.d.x, cr.d.y, cr.d.z, cr.p};
-    slots[2u * lane + 1u] = (RlV4){cr.m.x, cr.m.y, cr.m.z, cr.q};
+    ((RlLdsV4*)&ws->terms_d[0][0])[lane] = (RlV4){cr.d.x, cr.d.y, cr.d.z, cr.p};
+    ((RlLdsV4*)&ws->terms_m[0][0])[lane] = (RlV4){cr.m.x, cr.m.y, cr.m.z, cr.q};
     ((RlLdsF*)&ws->far[0])[lane] = far;
 }
 // ... and the OWNER lane's, for a round: two 16-byte gathers and a 4-byte one (the caller has passed a wave sync since the store).
 __device__ __forceinline__ void rl_fetch_cull_ray(RlWaveScratch* ws, uint32_t owner, RlCullRay& r, float& r_far) {
-    const RlLdsV4* slots = (const RlLdsV4*)&ws->terms[0][0];
-    const RlV4 a = slots[2u * owner], b = slots[2u * owner + 1u];
+    const RlV4 a = ((const RlLdsV4*)&ws->terms_d[0][0])[owner], b = ((const RlLdsV4*)&ws->terms_m[0][0])[owner];
     r_far = ((const RlLdsF*)&ws->far[0])[owner];
     r.d = rl_f3(a.x, a.y, a.z);
     r.p = a.w;
     r.m = rl_f3(b.x, b.y, b.z);
     r.q = b.w;
     r.len = 0.0f;
+}
+// The OWNER lane's ray for an exact round (sphere tails, prisms): its origin out of the cull terms -- m = -2 o, and halving is exact
+// (a denormal component of o would not come back, but scene coordinates are not denormals: every parity test runs through this) --
+// and its direction across lanes: one 16-byte gather and three ds_bpermute_b32 instead of six.
+__device__ __forceinline__ void rl_fetch_ray(RlWaveScratch* ws, uint32_t owner, RlF3 dir, RlF3& ro, RlF3& rd) {
+    const RlV4 b = ((const RlLdsV4*)&ws->terms_m[0][0])[owner];
+    rl_fetch3(owner, dir.x, dir.y, dir.z, rd.x, rd.y, rd.z);
+    ro = rl_f3(b.x * -0.5f, b.y * -0.5f, b.z * -0.5f);
 }
 
 // Open launches: per-workgroup LDS area behind the waves' scratch.
@@ -415,6 +422,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                  (unsigned long long)(best.obj == RL_HIT_NONE ? 0xffffffffu : (best.obj << 3));
     RL_T1(RL_ST_T_SMALL, t_small);
 
+    // The ray's cull terms (RlCullRay) and its far bound -- the nearest hit so far: here the planes, circles and paraboloids (in
+    // the built-in scene the floor, the walls and the ceiling: every ray has one), before the prisms also the spheres -- go to this
+    // lane's slots of the wave's scratch, where the rounds' lanes find them (behind their wave sync): every round below, the
+    // sphere tails of the direct list included, reads its pairs' rays from there.
+    RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
+    float far = best.t * cr.len;
+    rl_store_cull_ray(ws, lane, cr, far);
+
     // ---- ring B round: exact sphere tail for (record position, owner) pairs ----
     auto process_spheres = [&](uint32_t count) {
         RL_STAT(RL_ST_B_ROUNDS, 1);
@@ -431,8 +446,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         float s_r2;     // (a clustered sphere's s.w is its cull term)
         uint32_t s_obj;
         if (RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos], s_obj = sv.sphere_obj[pos];
-        float ox, oy, oz, dx, dy, dz;
-        rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ox, oy, oz, dx, dy, dz);
+        RlF3 fo, fd;
+        rl_fetch_ray(ws, owner, dir, fo, fd);
+        const float ox = fo.x, oy = fo.y, oz = fo.z, dx = fd.x, dy = fd.y, dz = fd.z;
         if (lane < count) {
             if (!RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos];
             const float cox = s.x - ox, coy = s.y - oy, coz = s.z - oz;
@@ -442,7 +458,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             const float sq = rl_sqrtf(q, true); // |q| is rooted: a miss of the pre-tested pair (q < 0, geometry.rs:213-215) is tested for itself
             const float t1 = dd - sq;
             const float t2 = dd + sq;
-            if (q >= 0.0f && t1 > 0.0f && t1 < t2) {
+            if ((q >= 0.0f) & (t1 > 0.0f) & (t1 < t2)) {
                 const uint32_t obj = RL_W_B ? s_obj : sv.sphere_obj[pos];
                 __hip_atomic_fetch_min(keys + owner, ((unsigned long long)rl_f2u(t1) << 32) | (unsigned long long)(obj << 3),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -499,11 +515,6 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     RL_T1(RL_ST_T_DIRECT, t_direct);
 
     RL_T0(t_cluster);
-    RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
-    // Far bound of the cull: the nearest hit so far -- here the planes, circles and paraboloids (in the built-in scene
-    // the floor, the walls and the ceiling: every ray has one), before the prisms also the spheres.
-    float far = best.t * cr.len;
-    rl_store_cull_ray(ws, lane, cr, far); // (read by the rounds' lanes, behind their wave sync)
     // ---- ring A round for clusters: each lane runs one (cluster, ray) pair over the members.  The members are
     // tested with the cull's own arithmetic -- on the device a clustered sphere's record is {centre, |c|^2 - R^2}, see
     // RlSceneView::sphere_r2 -- (8 FMAs, a v_med3 and a compare per member, far bound included) -- a conservative pre-test: ring B re-evaluates the pairs that pass with the
@@ -522,7 +533,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const uint32_t e = ring_a[(a_lim - 64u + slot) & 127u];
         const uint32_t owner = e & 63u;
         // lanes beyond the round hold stale ring entries: point them at cluster 0 so their (ignored) loads stay in bounds
-        uint32_t first = sv.cluster_base + (cluster_k + 1u) * (slot < count ? (e >> 6) : 0u) + 1u;
+        uint32_t first = sv.cluster_base + __umul24(cluster_k + 1u, slot < count ? (e >> 6) : 0u) + 1u; // (24-bit multiply: full rate)
         if (split) first += (lane >> 5) * (n_members >> 1);
         RlF4 mb;
         if (RL_W_M) mb = sph[first]; // (ahead of the cross-lane fetch: one wait for both)
@@ -621,7 +632,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();                                                                                 \
         const uint32_t e = ring_s[(s_lim - 64u + lane) & 127u];                                              \
         const uint32_t owner = e & 63u;                                                                 \
-        const uint32_t first = (ITEM_BASE) + (G) * ((lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
+        const uint32_t first = (ITEM_BASE) + __umul24((G), (lane < (COUNT)) ? (e >> 6) : 0u); /* stale entries: group 0 */ \
         /* (UNROLL_S: the children's bounds depend on the ring entry alone and are requested ahead of the cross-lane fetch, \
            whose wait covers them -- three LDS round trips less per round; the table has slack behind its last group) */ \
         RlF4 bnd_[4];                                                                                   \
@@ -703,18 +714,18 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
         RlF3 ro, rd;
-        rl_fetch6(owner, o.x, o.y, o.z, dir.x, dir.y, dir.z, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        rl_fetch_ray(ws, owner, dir, ro, rd);
         // The shortcut of rl_core.h decides all but ~0.1 % of the pairs (near an edge, grazing, within rounding of a face);
         // a round that holds one of those evaluates the reference's Compound tree instead -- for every lane, the branch is
         // wave-uniform, and with the same result for the lanes the shortcut had decided.
-        const RlF4* pr = sv.prisms + RL_PRISM_STRIDE * (lane < count ? prism : 0u);
+        const RlF4* pr = sv.prisms + __umul24((uint32_t)RL_PRISM_STRIDE, lane < count ? prism : 0u);
         RlCand c;
         int status = rl_hex_prism_fast<HOIST_S>(pr, ro, rd, &c); // (HOIST_S: the plain launches of a scene staged in LDS)
         if (lane >= count) status = RL_PRISM_MISS;
         if (__builtin_amdgcn_ballot_w64(status == RL_PRISM_UNSURE) != 0) {
             RL_STAT(RL_ST_P_SLOW, 1);
             c = rl_hex_prism(pr, ro, rd);
-            status = (lane < count && c.t >= 0.0f) ? RL_PRISM_HIT : RL_PRISM_MISS;
+            status = ((lane < count) & (c.t >= 0.0f)) ? RL_PRISM_HIT : RL_PRISM_MISS;
             // (the tree holds 8 normals, 8 offsets and 8 distances at once and sets the kernel's register count: this lane's own
             // cull terms are read back from the wave's scratch behind it instead of being held across it ...)
             {
@@ -728,7 +739,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             asm volatile("" : "+s"(again) : : "memory");
             e = ring_a[(again + lane) & 127u];
             owner = e & 63u;
-            pr = sv.prisms + RL_PRISM_STRIDE * (lane < count ? (e >> 6) : 0u);
+            pr = sv.prisms + __umul24((uint32_t)RL_PRISM_STRIDE, lane < count ? (e >> 6) : 0u);
         }
         if (status == RL_PRISM_HIT) {
             const uint32_t obj = rl_f2u(pr[1].w);
@@ -1279,7 +1290,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             segments += 1;
             float value;
             uint32_t emitter = 0;
-            const int status = rl_bounce(sv, job.seed, job.stream, my_path, &p, hit, &value, &emitter, (float*)ws->ring_b); // (ring B is empty between scans)
+            const int status = rl_bounce(sv, job.seed, job.stream, my_path, &p, hit, &value, &emitter);
             if (status != RL_PATH_CONTINUES) {
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
