@@ -177,6 +177,20 @@ def scene_of(R, config):
     return objs, cam, W, H, label
 
 
+def chip_shape():
+    """(CUs, SIMDs, XCDs) of the device the counters were collected on: the CU count from the device's properties (four SIMDs
+    per CU on CDNA), eight XCDs on MI300-class parts unless the counter files say otherwise (executed_live counts the
+    GRBM_GUI_ACTIVE instances).  ADVICE r04: not hard-coded at the use."""
+    cus = 256
+    try:
+        import torch
+        if torch.cuda.is_available():
+            cus = int(torch.cuda.get_device_properties(0).multi_processor_count)
+    except Exception:   # noqa: BLE001 -- no torch, no device: the MI355X figures
+        pass
+    return cus, 4 * cus, 8
+
+
 def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_per_launch=None):
     """The counter-derived half of the roofline, from the newest committed profiles/*_pmc.json that was measured
     on THIS build of the library and this workload (rl_build_id: a hash of the device code's sources).  The
@@ -200,8 +214,8 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
                                          % (os.path.relpath(path, ROOT), d.get("build_id"), R.build_id())}
     c = d["counters"]
     segs64 = d["rays_per_launch"] / 64.0
-    simds = 1024.0
-    cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / simds)
+    cus, simds, xcds = chip_shape()
+    cyc = (c["GRBM_GUI_ACTIVE"] / xcds) / (c["SQ_INSTS_VALU"] / simds)
     lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
     out = {
         "profile": os.path.relpath(path, ROOT), "build_id": d["build_id"],
@@ -213,11 +227,11 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
         "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
         # occupancy actually achieved: wave-cycles (a quad-cycle counter) per elapsed cycle and SIMD.  The compiler reports 118-120
         # VGPRs for this kernel, rocprofv3 "VGPR_Count 60" (the unified file counted in halves): 4 waves per SIMD either way.
-        "resident_waves_per_simd": (4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / simds) if c.get("SQ_WAVE_CYCLES") else None,
+        "resident_waves_per_simd": (4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / xcds) / simds) if c.get("SQ_WAVE_CYCLES") else None,
         # SQ_LDS_BANK_CONFLICT counts LDS-array cycles (one per extra address on a busy bank), summed over the CUs; GRBM_GUI_ACTIVE is
         # summed over the 8 XCDs: conflict cycles per CU-cycle = the share of time a CU's LDS spends on conflicts (round 3 divided
         # by SQ_ACTIVE_INST_LDS, a quad-cycle counter of something else -- VERDICT r03).  Attribution: profiles/r04_lds_conflicts.txt.
-        "lds_bank_conflict_cycles_per_cu_cycle": (c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0)) if c.get("SQ_LDS_BANK_CONFLICT") else None,
+        "lds_bank_conflict_cycles_per_cu_cycle": (c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / xcds * cus)) if c.get("SQ_LDS_BANK_CONFLICT") else None,
         "lds_bank_conflict_share_of_lds_array_cycles": (c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]) if c.get("SQ_LDS_IDX_ACTIVE") else None,
         "wave_time": ({"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                        "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]} if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAIT_ANY") else None),
@@ -259,7 +273,7 @@ def executed_live(args, committed, timeout_s=100.0):
     env = dict(os.environ, TMPDIR="/tmp", RL_BENCH_LIVE_CHILD="1")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--launches-per-step", "1", "--batches-per-launch", "256",
              "--config", args.config, "--fetch", args.fetch, "--seed", str(args.seed), "--no-cpu-baseline", "--no-others", "--no-live-counters"]
-    c, line, kernel_ns = {}, None, []
+    c, line, kernel_ns, instances = {}, None, [], {}
     try:
         for i, counters in enumerate(LIVE_PASSES):
             left = timeout_s - (time.perf_counter() - t_begin)
@@ -274,42 +288,52 @@ def executed_live(args, committed, timeout_s=100.0):
                 return {"skipped": "counter pass %d failed (rc %d): %s" % (i, run.returncode, run.stderr.decode(errors="replace")[-300:])}
             line = json.loads(lines[-1])
             d = collections.defaultdict(lambda: collections.defaultdict(float))
+            rows = collections.defaultdict(lambda: collections.defaultdict(int))
             ns = {}
             for r in csv.DictReader(open(files[0])):
                 if "rl_trace" in r["Kernel_Name"]:
                     d[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+                    rows[r["Dispatch_Id"]][r["Counter_Name"]] += 1
                     ns[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             if not d:
                 return {"skipped": "counter pass %d saw no trace kernel" % i}
             k = sorted(d, key=int)[-1]
             for name, v in d[k].items():
                 c.setdefault(name, v)     # (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE of the first pass that has them)
+                instances.setdefault(name, rows[k][name])
             kernel_ns.append(ns[k])
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
         return {"skipped": "counter pass failed: %r" % (e,)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    segs64 = line["roofline"]["rays_per_launch"] / 64.0
-    cyc = (c["GRBM_GUI_ACTIVE"] / 8.0) / (c["SQ_INSTS_VALU"] / 1024.0)
-    lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
-    live = {
-        "how": "rocprofv3 --pmc around `bench.py --steps 1 --launches-per-step 1 --batches-per-launch 256` of this config, run by this "
-               "process after its timed region: two passes, last rl_trace_kernel dispatch of each",
-        "build_id": line["config"]["build_id"],
-        "valu_insts_per_64ray_segment": c["SQ_INSTS_VALU"] / segs64,
-        "cycles_per_valu_inst_per_simd": cyc,
-        "issue_frac_vs_2cyc": 2.0 / cyc,
-        "active_lanes": lanes,
-        "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
-        "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
-        "resident_waves_per_simd": 4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0) / 1024.0,
-        "wave_time": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                      "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
-        "lds_bank_conflict_cycles_per_cu_cycle": c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256.0),
-        "lds_bank_conflict_share_of_lds_array_cycles": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
-        "profiled_launch_ms": sum(kernel_ns) / len(kernel_ns) / 1e6, "profiled_rays_per_launch": line["roofline"]["rays_per_launch"],
-        "seconds": time.perf_counter() - t_begin,
-    }
+    try:   # (a counter the profiler dropped, or one that reads zero, must not cost the bench its line)
+        segs64 = line["roofline"]["rays_per_launch"] / 64.0
+        cus, simds, xcds = chip_shape()
+        xcds = instances.get("GRBM_GUI_ACTIVE") or xcds   # (one GRBM instance per XCD; rocprofv3 may also report the sum as one row)
+        if instances.get("GRBM_GUI_ACTIVE") == 1:
+            xcds = chip_shape()[2]
+        cyc = (c["GRBM_GUI_ACTIVE"] / xcds) / (c["SQ_INSTS_VALU"] / simds)
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+        live = {
+            "how": "rocprofv3 --pmc around `bench.py --steps 1 --launches-per-step 1 --batches-per-launch 256` of this config, run by this "
+                   "process after its timed region: two passes, last rl_trace_kernel dispatch of each",
+            "build_id": line["config"]["build_id"],
+            "valu_insts_per_64ray_segment": c["SQ_INSTS_VALU"] / segs64,
+            "cycles_per_valu_inst_per_simd": cyc,
+            "issue_frac_vs_2cyc": 2.0 / cyc,
+            "active_lanes": lanes,
+            "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
+            "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
+            "resident_waves_per_simd": 4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / xcds) / simds,
+            "wave_time": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                          "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
+            "lds_bank_conflict_cycles_per_cu_cycle": c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / xcds * cus),
+            "lds_bank_conflict_share_of_lds_array_cycles": c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"] if c.get("SQ_LDS_IDX_ACTIVE") else None,
+            "profiled_launch_ms": sum(kernel_ns) / len(kernel_ns) / 1e6, "profiled_rays_per_launch": line["roofline"]["rays_per_launch"],
+            "seconds": time.perf_counter() - t_begin,
+        }
+    except (KeyError, ZeroDivisionError, TypeError) as e:
+        return {"skipped": "counter derivation failed: %r" % (e,)}
     if committed and not committed.get("stale"):
         keys = ("valu_insts_per_64ray_segment", "cycles_per_valu_inst_per_simd", "active_lanes", "useful_lane_slots_vs_2cyc")
         live["vs_committed"] = {k: live[k] / committed[k] for k in keys}

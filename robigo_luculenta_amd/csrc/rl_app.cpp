@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>  // open(O_DIRECTORY): the fsync of a directory behind a rename
 #include <unistd.h> // fsync
 
 #include "../../include/robigo_luculenta.h"
@@ -182,7 +183,19 @@ std::string sidecar_path(const char* checkpoint) { return std::string(checkpoint
 // Both files are replaced atomically (written beside themselves, then renamed), the index FIRST: a crash between the
 // two leaves a newer index beside an older buffer -- the samples in between are lost, which is noise, whereas the other
 // order would add them twice on resume, which is bias.
-int replace_file(const std::string& tmp, const std::string& path) { return std::rename(tmp.c_str(), path.c_str()) == 0 ? RL_OK : RL_E_IO; }
+// The rename itself is made durable too: a rename lives in the directory, and without an fsync of the directory the
+// kernel may persist two renames in either order -- the buffer's could reach the disk with the old index still in place, and a
+// resume after a power loss would then add those samples a second time.
+int replace_file(const std::string& tmp, const std::string& path) {
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) return RL_E_IO;
+    const size_t slash = path.find_last_of('/');
+    const std::string dir = slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : path.substr(0, slash));
+    const int fd = open(dir.c_str(), O_RDONLY | O_DIRECTORY);
+    if (fd < 0) return RL_E_IO;
+    const bool ok = fsync(fd) == 0;
+    close(fd);
+    return ok ? RL_OK : RL_E_IO;
+}
 
 std::vector<ResumeEntry> read_sidecar(const char* checkpoint, uint32_t photons, const RlAppConfig* config, size_t ranks) {
     std::vector<ResumeEntry> entries;
@@ -216,7 +229,8 @@ int save_checkpoint(AppState& a) {
                  (unsigned long long)a.cfg->seed, a.cfg->stream, a.ranks.size());
     for (const ResumeEntry& e : a.other_samples) // what the buffer already held of other seeds / streams when this run loaded it
         std::fprintf(f, "next_batch %llu\nphotons_per_batch %u\nseed %llu\nstream %u\nranks %zu\n", e.next, e.ppb, e.seed, e.stream, e.ranks);
-    // on disk before the rename makes it the index: the index-before-buffer order must survive a power loss, not only a crash
+    // on disk before the rename makes it the index, and the rename on disk (replace_file) before the buffer is touched: the
+    // index-before-buffer order must survive a power loss, not only a crash
     const bool flushed = std::fflush(f) == 0 && fsync(fileno(f)) == 0;
     if (std::fclose(f) != 0 || !flushed) return RL_E_IO;
     int rc = replace_file(side_tmp, side);

@@ -1221,25 +1221,33 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 continue;
             }
             const uint32_t rank = rl_mbcnt(need);
-            if (!active && rank < avail) {
-                const uint32_t slot = stash_head + rank;
-                if (slot < stash_valid) {
-                    my_path = stash_path0 + slot;
-                    if (OPEN) my_job = stash_job;
-                    p.origin = rl_f3(stash[0 * 64 + slot], stash[1 * 64 + slot], stash[2 * 64 + slot]);
-                    p.direction = rl_f3(stash[3 * 64 + slot], stash[4 * 64 + slot], stash[5 * 64 + slot]);
-                    p.wavelength = stash[6 * 64 + slot];
-                    p.sx = stash[7 * 64 + slot];
-                    p.sy = stash[8 * 64 + slot];
-                    p.ior = stash[9 * 64 + slot];
-                    p.intensity = 1.0f;
-                    p.continue_chance = 1.0f;
-                    p.bounce = 0;
-                    active = true;
-                }
+            const uint32_t slot = stash_head + rank;
+            // One condition, combined without branches, and selects instead of assignments under it: with the sixteen assignments
+            // inside (nested) ifs the compiler copied the whole path state at every join -- 64 v_mov per iteration.  Every lane
+            // reads a slot (the lanes that take nothing: any one), the takers keep what they read.
+            const bool take = !active & (rank < avail) & (slot < stash_valid);
+            {
+                const uint32_t sl = slot & 63u;
+                const float s0 = stash[0 * 64 + sl], s1 = stash[1 * 64 + sl], s2 = stash[2 * 64 + sl], s3 = stash[3 * 64 + sl], s4 = stash[4 * 64 + sl];
+                const float s5 = stash[5 * 64 + sl], s6 = stash[6 * 64 + sl], s7 = stash[7 * 64 + sl], s8 = stash[8 * 64 + sl], s9 = stash[9 * 64 + sl];
+                my_path = take ? stash_path0 + slot : my_path;
+                if (OPEN) my_job = take ? stash_job : my_job;
+                p.origin = rl_f3(take ? s0 : p.origin.x, take ? s1 : p.origin.y, take ? s2 : p.origin.z);
+                p.direction = rl_f3(take ? s3 : p.direction.x, take ? s4 : p.direction.y, take ? s5 : p.direction.z);
+                p.wavelength = take ? s6 : p.wavelength;
+                p.sx = take ? s7 : p.sx;
+                p.sy = take ? s8 : p.sy;
+                p.ior = take ? s9 : p.ior;
+                p.intensity = take ? 1.0f : p.intensity;
+                p.continue_chance = take ? 1.0f : p.continue_chance;
+                p.bounce = take ? 0u : p.bounce;
+                active = active | take;
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
             stash_head += wanted < avail ? wanted : avail;
+            // (the common case leaves here instead of through a second pass of the loop's head: every lane that asked was given a
+            // slot -- one without a path, at the tail of a launch, asks again in the next iteration)
+            if (RL_LIKELY(wanted <= avail)) break;
         }
         RL_T1(RL_ST_T_REFILL, t_refill);
         if (__builtin_amdgcn_ballot_w64(active) == 0) {

@@ -32,15 +32,18 @@ struct RlRngBlock {
 RL_HD uint32_t rl_mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
 
 #define RL_PHILOX_ROUNDS 7
-template <int ROUNDS>
+// UNIFORM_KEY (device): the caller guarantees that the key is the same in every lane of the wave (rl_rng_block: the launch's
+// seed).  Only then may the key be pinned to scalar registers -- a per-lane key forced through an "s" constraint would silently
+// become lane 0's -- so the public rl_philox4x32_10 and every other caller leave it false.
+template <int ROUNDS, bool UNIFORM_KEY = false>
 RL_HD RlRngBlock rl_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #if defined(__HIP_DEVICE_COMPILE__)
     // The key (the launch's seed) is wave-uniform and loop-invariant over the trace kernel's persistent loop: left alone, the
     // optimiser hoists the whole key schedule -- 18 sums key + round * W -- out of that loop into scalar registers that
     // then do not fit (spilled to lanes of a vector register and read back with v_readlane).  Opaque here, the schedule
-    // is 18 s_add_i32 per block on the otherwise idle scalar unit.
-    asm volatile("" : "+s"(k0), "+s"(k1));
+    // is 18 s_add_i32 per block on the scalar unit.
+    if (UNIFORM_KEY) asm volatile("" : "+s"(k0), "+s"(k1));
 #endif
 #if defined(__HIPCC__)
 #pragma unroll
@@ -79,9 +82,9 @@ RL_HD RlRngBlock rl_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
     return rl_philox4x32<10>(c0, c1, c2, c3, k0, k1); // the published variant: known-answer tests
 }
 
-// One block of draws for (seed, stream, path, block).
+// One block of draws for (seed, stream, path, block).  `seed` is the launch's seed: the same in every lane (UNIFORM_KEY).
 RL_HD RlRngBlock rl_rng_block(uint64_t seed, uint32_t stream, uint64_t path, uint32_t block) {
-    return rl_philox4x32<RL_PHILOX_ROUNDS>((uint32_t)path, (uint32_t)(path >> 32), block, stream, (uint32_t)seed,
+    return rl_philox4x32<RL_PHILOX_ROUNDS, true>((uint32_t)path, (uint32_t)(path >> 32), block, stream, (uint32_t)seed,
                                            (uint32_t)(seed >> 32));
 }
 

@@ -97,6 +97,19 @@ def test_sf10_index_decided_from_the_cheap_evaluation_is_the_reference_f64_expre
         assert got.view(np.uint32).tobytes() == want.view(np.uint32).tobytes()
 
 
+def _exhaustive_slices(lo, hi, step):
+    """The slices of [lo, hi) an exhaustive sweep visits.  RL_EXHAUSTIVE=1: all of them (1.9 G / 3.4 G floats through the probe and
+    numpy: minutes and many GB of host traffic -- what tools/sqrt_exhaustive.hip does on the device in seconds, and what
+    profiles/r04_sqrt_exhaustive.txt records).  By default: every eighth slice, rotating with the day so that the
+    suite's runs cover all of them between them, plus the first and the last."""
+    firsts = list(range(lo, hi, step))
+    if os.environ.get("RL_EXHAUSTIVE"):
+        return firsts
+    import datetime
+    phase = datetime.date.today().toordinal() % 8
+    return sorted(set(firsts[phase::8]) | {firsts[0], firsts[-1]})
+
+
 def test_short_square_root_is_the_ieee_one_for_every_normal_float():
     """rl_sqrtf (rl_core.h): y = v_rsq_f32(x), s = x y, s + (x - s s) y / 2 -- four operations after the hardware's inverse
     square root -- in place of the compiler's 16-instruction correctly rounded expansion, for waves whose arguments are all
@@ -105,7 +118,7 @@ def test_short_square_root_is_the_ieee_one_for_every_normal_float():
     NaN, negatives) must take the compiler's form and give the IEEE result too."""
     lo, hi = 0x0f800000, 0x7f800000
     step = 1 << 25
-    for first in range(lo, hi, step):
+    for first in _exhaustive_slices(lo, hi, step):
         x = np.arange(first, min(first + step, hi), dtype=np.uint32).view(np.float32)
         got = R.math_probe("sqrt_short", x)
         assert got.view(np.uint32).tobytes() == np.sqrt(x).view(np.uint32).tobytes(), hex(first)
@@ -128,7 +141,7 @@ def test_short_one_operand_divisions_are_the_ieee_ones(fn):
     ref = (lambda x: np.float32(1.0) / x) if fn == "recip_short" else (lambda x: x / np.float32(200.0))
     lo, hi = 0x0d800000, 0x71800000
     step = 1 << 25
-    for first in range(lo, hi, step):
+    for first in _exhaustive_slices(lo, hi, step):
         x = np.arange(first, min(first + step, hi), dtype=np.uint32).view(np.float32)
         assert R.math_probe(fn, x).view(np.uint32).tobytes() == ref(x).view(np.uint32).tobytes(), hex(first)
     rng = np.random.default_rng(6)
