@@ -1037,6 +1037,53 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             asm volatile("s_cmp_eq_u32 0, 1");
 #pragma unroll
             for (int k = 0; k < 64; ++k) asm volatile("s_cbranch_scc1 0");
+#elif RL_EXP_EXTRA == 6 // 128 packed FMAs (four chains)
+            {
+                typedef float F2 __attribute__((ext_vector_type(2)));
+                F2 pa = {(float)lane, 1.0f}, pb = {2.0f, (float)lane}, pc = {3.0f, 1.5f}, pd = {0.5f, 0.25f};
+#pragma unroll
+                for (int k = 0; k < 32; ++k) asm volatile("v_pk_fma_f32 %0, %0, %1, %2\n\tv_pk_fma_f32 %1, %1, %2, %3\n\tv_pk_fma_f32 %2, %2, %3, %0\n\tv_pk_fma_f32 %3, %3, %0, %1" : "+v"(pa), "+v"(pb), "+v"(pc), "+v"(pd));
+                xv = rl_f2u(pa.x + pb.y + pc.x + pd.y);
+            }
+#elif RL_EXP_EXTRA == 7 // 256 scalar-operand-free FMAs (four chains)
+            {
+                float fa = (float)lane, fb = 2.0f, fc = 3.0f, fd = 0.5f;
+#pragma unroll
+                for (int k = 0; k < 64; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %1, %1, %2, %3\n\tv_fma_f32 %2, %2, %3, %0\n\tv_fma_f32 %3, %3, %0, %1" : "+v"(fa), "+v"(fb), "+v"(fc), "+v"(fd));
+                xv = rl_f2u(fa + fb + fc + fd);
+            }
+#elif RL_EXP_EXTRA == 10 // 4 batches of nine ds_bpermute_b32 with one wait each (how rounds 1-4 fetched a pair's ray)
+            {
+                float t0 = (float)lane;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t addr = ((lane * 7u + 3u) & 63u) << 2;
+                    float r0, r1, r2, r3, r4, r5, r6, r7, r8;
+                    asm volatile("ds_bpermute_b32 %0, %9, %10\n\tds_bpermute_b32 %1, %9, %10\n\tds_bpermute_b32 %2, %9, %10\n\t"
+                                 "ds_bpermute_b32 %3, %9, %10\n\tds_bpermute_b32 %4, %9, %10\n\tds_bpermute_b32 %5, %9, %10\n\t"
+                                 "ds_bpermute_b32 %6, %9, %10\n\tds_bpermute_b32 %7, %9, %10\n\tds_bpermute_b32 %8, %9, %10\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8)
+                                 : "v"(addr), "v"(t0) : "memory");
+                    t0 = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + r8;
+                }
+                xv = rl_f2u(t0);
+            }
+#elif RL_EXP_EXTRA == 12 // 4 batches of two 16-byte gathers + one 4-byte gather from the wave's scratch, one wait each (round 5's fetch)
+            {
+                float t0 = (float)lane;
+                uint32_t who = (lane * 7u + 3u) & 63u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    RlCullRay r;
+                    float f;
+                    rl_fetch_cull_ray(ws, who, r, f);
+                    t0 += r.d.x + r.d.y + r.d.z + r.p + r.m.x + r.m.y + r.m.z + r.q + f;
+                    who = (who * 5u + (rl_f2u(t0) & 1u)) & 63u;
+                    asm volatile("" ::: "memory");
+                }
+                xv = rl_f2u(t0);
+            }
 #elif RL_EXP_EXTRA == 11 // 64 s_and_saveexec / s_or exec pairs
 #pragma unroll
             for (int k = 0; k < 64; ++k) asm volatile("s_and_saveexec_b64 s[2:3], exec\n\ts_or_b64 exec, exec, s[2:3]" ::: "s2", "s3");

@@ -41,5 +41,7 @@ timeout 300 python tools/open_launch_stress.py > $OUT/open_launch_stress.txt 2>&
 timeout 900 tools/valu_mb > $OUT/valu_microbench.txt 2>&1
 bash tools/lds_conflicts.sh $TAG > /dev/null 2>&1
 bash tools/pmc_stalls.sh $TAG demo-1080p > $OUT/instruction_mix.txt 2>&1; bash tools/pmc_stalls.sh $TAG glass-720p >> $OUT/instruction_mix.txt 2>&1
+# every kind of instruction per 64-ray segment and the split of a wave's time (round 5: what the kernel's time is made of)
+for CF in "demo-1080p lds" "glass-720p lds" "replicated-1080p lds" "replicated-1080p global"; do set -- $CF; bash tools/pmc_mix.sh $TAG $1 $2 | grep -v "^\[" ; done > $OUT/wave_time.txt 2>&1
 cat $OUT/app.txt $OUT/big_parity.txt $OUT/image_parity.txt
 tail -12 gpurun_out/${TAG}_console.txt | cut -c1-400

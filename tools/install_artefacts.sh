@@ -20,6 +20,8 @@ cp $SRC/open_launch_stress.txt profiles/${TAG}_open_launch_stress.txt
 [ -f $SRC/lds_conflicts.txt ] && cp $SRC/lds_conflicts.txt profiles/${TAG}_lds_conflicts.txt
 [ -f $SRC/instruction_mix.txt ] && cp $SRC/instruction_mix.txt profiles/${TAG}_instruction_mix.txt
 [ -f $SRC/app_soak.txt ] && cp $SRC/app_soak.txt profiles/${TAG}_app_soak.txt
+[ -f $SRC/wave_time.txt ] && cp $SRC/wave_time.txt profiles/${TAG}_wave_time.txt
+[ -f $SRC/issue_cost_probes.txt ] && cp $SRC/issue_cost_probes.txt profiles/${TAG}_issue_cost_probes.txt
 python - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]
