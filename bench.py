@@ -228,6 +228,9 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
         # occupancy actually achieved: wave-cycles (a quad-cycle counter) per elapsed cycle and SIMD.  The compiler reports 118-120
         # VGPRs for this kernel, rocprofv3 "VGPR_Count 60" (the unified file counted in halves): 4 waves per SIMD either way.
         "resident_waves_per_simd": (4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / xcds) / simds) if c.get("SQ_WAVE_CYCLES") else None,
+        # round 5: a wave's time goes into issuing instructions of EVERY kind (and into LDS round trips) -- DESIGN.md 4.2
+        "insts_per_64ray_segment": (c["SQ_INSTS"] / segs64) if c.get("SQ_INSTS") else None,
+        "wave_cycles_per_inst": (4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_INSTS"]) if c.get("SQ_INSTS") and c.get("SQ_WAVE_CYCLES") else None,
         # SQ_LDS_BANK_CONFLICT counts LDS-array cycles (one per extra address on a busy bank), summed over the CUs; GRBM_GUI_ACTIVE is
         # summed over the 8 XCDs: conflict cycles per CU-cycle = the share of time a CU's LDS spends on conflicts (round 3 divided
         # by SQ_ACTIVE_INST_LDS, a quad-cycle counter of something else -- VERDICT r03).  Attribution: profiles/r04_lds_conflicts.txt.
@@ -250,7 +253,7 @@ def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_pe
 
 
 LIVE_PASSES = (
-    "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE",
+    "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS SQ_INSTS_SALU GRBM_GUI_ACTIVE",
     "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES GRBM_GUI_ACTIVE",
 )
 
@@ -325,6 +328,8 @@ def executed_live(args, committed, timeout_s=100.0):
             "useful_lane_slots_vs_2cyc": 2.0 / cyc * lanes,
             "salu_insts_per_64ray_segment": c.get("SQ_INSTS_SALU", 0.0) / segs64,
             "resident_waves_per_simd": 4.0 * c["SQ_WAVE_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / xcds) / simds,
+            "insts_per_64ray_segment": (c["SQ_INSTS"] / segs64) if c.get("SQ_INSTS") else None,
+            "wave_cycles_per_inst": (4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_INSTS"]) if c.get("SQ_INSTS") else None,
             "wave_time": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stalled": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                           "waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
             "lds_bank_conflict_cycles_per_cu_cycle": c["SQ_LDS_BANK_CONFLICT"] / (c["GRBM_GUI_ACTIVE"] / xcds * cus),
@@ -741,7 +746,10 @@ def main():
                          "traffic_note": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB of the profile named in `executed`, scaled to this run's paths per launch "
                                          "(each f32 atomic is billed as one 32-byte write); algorithmic: 48 B per contributing path; "
                                          "null when the profile is stale",
-                         "note": "VALU-issue bound (no dense contraction -> no MFMA); HBM traffic is the XYZ splat only"},
+                         "note": "no dense contraction -> no MFMA; HBM traffic is the XYZ splat only.  The kernel is bound by what a WAVE can issue at four waves "
+                                 "per SIMD: a wave's time is ~50 % issuing instructions (vector, scalar and LDS instructions cost it alike, a taken branch two), "
+                                 "~30 % waiting for LDS round trips, ~20 % issue-stalled; the vector ALU is ~68 % busy (valu_busy).  DESIGN.md 4.2, "
+                                 "profiles/r05_issue_cost_probes.txt"},
         }
         if world == 1 and not args.no_others:
             out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]

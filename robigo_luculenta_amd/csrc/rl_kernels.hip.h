@@ -12,16 +12,22 @@
 //     paths per wave) drains;
 //   * the scan (rl_scan_wave) runs only cheap reject / cull tests lane-per-ray; every expensive tail
 //     (sphere roots, cluster members, prisms) is compacted with ballot/mbcnt into LDS rings and
-//     evaluated 64 (item, ray) pairs at a time, results min-merged per ray with ds_min_u64;
+//     evaluated 64 (item, ray) pairs at a time -- a pair's lane gathers its ray from the owner lane's slot of the
+//     wave's LDS scratch -- results min-merged per ray with ds_min_u64;
 //   * results leave either as MappedPhoton records (un-fused, bit-comparable with the CPU) or as
 //     12 hardware f32 atomics per contributing path into the XYZ buffer (fused TraceUnit+PlotUnit);
 //     in fused mode the paths that ended on a light wait in a per-wave LDS queue until 64 of them can
 //     be evaluated (f64 Planck term) and splatted with a full exec mask;
-//   * no MFMA: there is no dense contraction in this workload; the bound is VALU issue at the kernel's instruction mix
-//     (one instruction per 3.3 cycles per SIMD: 70 % full-rate, 27 % half-rate, 1.4 % transcendental);
+//   * no MFMA: there is no dense contraction in this workload.  What bounds it (round 5; probes in this file under
+//     RL_EXP_EXTRA): not the vector ALU's lanes but what ONE WAVE can issue -- at four waves per SIMD a wave spends half of its
+//     time issuing instructions, vector, scalar and LDS alike (a scalar instruction costs what a vector one does, a packed FMA
+//     two, a taken branch two), a third waiting for LDS round trips (an exposed one costs ten instructions, a ds_bpermute_b32
+//     five) and a fifth issue-stalled.  Hence: record loads issued ahead of the data they are used with, the rays' cull terms
+//     gathered from LDS slots instead of permuted across lanes, conditions combined without branches, ring pushes in four
+//     vector instructions -- and no attention to lane occupancy for its own sake;
 //   * OPEN variant: the kernel stays resident and takes the paths of blocking render calls from a job table the host
-//     appends to while it runs (RlOpenDev / RlOpenCtl below); at most 120 VGPRs so that the small kernels of the other
-//     units run beside it.
+//     appends to while it runs (RlOpenDev / RlOpenCtl below): rl_trace_kernel_open, at most 120 VGPRs so that the small
+//     kernels of the other units run beside it (the plain launches, rl_trace_kernel, may use all 128).
 #pragma once
 #include <hip/hip_runtime.h>
 

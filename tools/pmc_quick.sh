@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-cpu-baseline --no-others --no-live-counters --config $CFG --fetch $FETCH"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_valu_$CFG-$FETCH -o p -- python bench.py $ARGS > $OUT/pmc_valu_$CFG-$FETCH.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS SQ_INSTS_SALU GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_valu_$CFG-$FETCH -o p -- python bench.py $ARGS > $OUT/pmc_valu_$CFG-$FETCH.log 2>&1
 grep '^{' $OUT/pmc_valu_$CFG-$FETCH.log | tail -1 > $OUT/pmc_bench_$CFG-$FETCH.json
 python - <<PY
 import csv, json, collections
