@@ -394,6 +394,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #define RL_SMALL_PRIMITIVES(NEARER)                                                                   \
     for (uint32_t i = 0; i < n_parabs; ++i) {                                                         \
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];       \
+        if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* records in LDS: 16-byte loads (rl_hex_prism_fast), a 12-byte LDS read takes twice the LDS time */ \
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);                  \
         const uint32_t obj = rl_f2u(r0.w);                                                            \
         if (!(t < 0.0f) && NEARER(t, obj, best)) {                                                    \
@@ -726,7 +727,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // wave-uniform, and with the same result for the lanes the shortcut had decided.
         const RlF4* pr = sv.prisms + __umul24((uint32_t)RL_PRISM_STRIDE, lane < count ? prism : 0u);
         RlCand c;
-        int status = rl_hex_prism_fast<HOIST_S>(pr, ro, rd, &c); // (HOIST_S: the plain launches of a scene staged in LDS)
+        int status = rl_hex_prism_fast<HOIST_S && SPLIT>(pr, ro, rd, &c); // (the plain launches of a scene whose prisms are staged in LDS)
         if (lane >= count) status = RL_PRISM_MISS;
         if (__builtin_amdgcn_ballot_w64(status == RL_PRISM_UNSURE) != 0) {
             RL_STAT(RL_ST_P_SLOW, 1);
