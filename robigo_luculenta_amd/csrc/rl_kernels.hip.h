@@ -602,7 +602,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const RlF4 bnd = (BND);                                                                         \
         const bool pass = rl_cull_pass(r, bnd, r_far);                                                  \
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                           \
-        if (m != 0) {                                                                                   \
+        { /* (no `if (m != 0)`: some pair of the round passes practically every child) */               \
             const uint32_t entry = ((first + (J) - (ITEM_BASE)) << 6) | owner;                          \
             RL_PUSH_##CYL(entry, PROCESS_A)                                                             \
         }                                                                                               \
@@ -675,13 +675,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
                test ahead into registers of its own it had to be COPIED over g0 every time round -- four moves and an address \
                per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
             g0 = gb[g + 1];                                                                             \
-            if (m != 0) {                                                                               \
-                if (pass) *RL_RING_SLOT(ring_s, m, s_tail) = (g << 6) | lane; /* group number within its kind */ \
-                s_tail += (uint32_t)__popcll(m);                                                        \
-                if (RL_UNLIKELY(s_tail >= s_lim)) {                                                           \
-                    RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                   \
-                    s_lim += 64u;                                                                      \
-                }                                                                                       \
+            /* (no `if (m != 0)` around the push: with 64 rays per wave some lane passes practically every group bound, and the   \
+               test would be one more instruction per group) */                                         \
+            if (pass) *RL_RING_SLOT(ring_s, m, s_tail) = (g << 6) | lane; /* group number within its kind */ \
+            s_tail += (uint32_t)__popcll(m);                                                            \
+            if (RL_UNLIKELY(s_tail >= s_lim)) {                                                         \
+                RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                       \
+                s_lim += 64u;                                                                           \
             }                                                                                           \
         }                                                                                               \
         if (s_tail != s_lim - 64u) {                                                                    \
