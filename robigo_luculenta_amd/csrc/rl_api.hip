@@ -432,15 +432,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_prism_cyl = append(fs.prism_cyl);
     lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
     lay.group_gc = fs.group_gc;
-    {   // both lists are in object order (rl_flatten_scene appends them object by object); ordered against each other?
-        uint32_t last_parab = 0, first_plane = 0xffffffffu;
-        for (size_t i = 0; i < fs.parabs.size(); i += 3) last_parab = std::max(last_parab, rl_f2u(fs.parabs[i].w));
-        for (size_t i = 1; i < fs.planes.size(); i += 2) first_plane = std::min(first_plane, rl_f2u(fs.planes[i].w));
-        bool sorted = fs.parabs.empty() || fs.planes.empty() || last_parab < first_plane;
-        for (size_t i = 3; i < fs.parabs.size(); i += 3) sorted = sorted && rl_f2u(fs.parabs[i - 3].w) < rl_f2u(fs.parabs[i].w);
-        for (size_t i = 3; i < fs.planes.size(); i += 2) sorted = sorted && rl_f2u(fs.planes[i - 2].w) < rl_f2u(fs.planes[i].w);
-        lay.small_ordered = sorted ? 1u : 0u;
-    }
+    lay.small_ordered = fs.small_ordered ? 1u : 0u;
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     // ... then the per-object arrays

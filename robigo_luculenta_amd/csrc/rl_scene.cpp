@@ -1033,6 +1033,15 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     }
     fs.cull_bounds.push_back(dummy); // slack for the kernel's prefetch
     fs.cull_bounds.push_back(dummy);
+    {   // RlFlatScene::small_ordered (both lists were appended object by object: checked all the same)
+        uint32_t last_parab = 0, first_plane = 0xffffffffu;
+        for (size_t i = 0; i < fs.parabs.size(); i += 3) last_parab = std::max(last_parab, rl_f2u(fs.parabs[i].w));
+        for (size_t i = 1; i < fs.planes.size(); i += 2) first_plane = std::min(first_plane, rl_f2u(fs.planes[i].w));
+        bool sorted = fs.parabs.empty() || fs.planes.empty() || last_parab < first_plane;
+        for (size_t i = 3; i < fs.parabs.size(); i += 3) sorted = sorted && rl_f2u(fs.parabs[i - 3].w) < rl_f2u(fs.parabs[i].w);
+        for (size_t i = 3; i < fs.planes.size(); i += 2) sorted = sorted && rl_f2u(fs.planes[i - 2].w) < rl_f2u(fs.planes[i].w);
+        fs.small_ordered = sorted;
+    }
     // The clustered spheres in the cull's form: the fourth component a cluster-member record carries on the DEVICE
     // instead of radius^2 (rl_api.hip swaps it in; the exact radius^2 goes to a separate float array that only the exact
     // tail reads).  The cluster-member rounds of the kernel use it as a conservative pre-test -- the reference arithmetic

@@ -97,6 +97,10 @@ struct RlFlatScene {
     bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene
     float cull_cmax2; // max |centre|^2 over cull_bounds (scales the cull's rounding slack)
+    // The paraboloids' objects all precede the planes' and circles', and each list is in object order: the kernel's scan of the
+    // small primitives (paraboloids, then planes) then visits objects in ascending order and `t < best.t` alone is scene.rs:51's
+    // "the first object wins a tie" (RlSceneLayout::small_ordered; the built-in scenes).  Other scenes take the general compare.
+    bool small_ordered = false;
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters, cluster_k; // see RlSceneView
     RlCameraDesc camera;

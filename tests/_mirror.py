@@ -101,6 +101,14 @@ def plot(w, h, photons):
     return buffer
 
 
+def small_ordered(scene):
+    """RlFlatScene::small_ordered of `scene`: the kernel may take `t < best.t` for scene.rs:51's tie rule among the small primitives."""
+    L = lib()
+    L.mirror_small_ordered.restype = C.c_int
+    L.mirror_small_ordered.argtypes = [C.c_void_p]
+    return bool(L.mirror_small_ordered(scene.h))
+
+
 def cull_counts(scene, w, h, seed, stream, first, n):
     """What the kernel's sphere pass does with `scene`'s cull table on the segments of paths [first, first + n), counted on
     the host: per segment the (group, ray), (cluster, ray) and (member, ray) pairs that pass, and the table's shape."""

@@ -363,6 +363,9 @@ static bool mirror_reach(RlF4 b, RlF3 o, RlF3 dir, double far_t) {
     const double px = cox - x * dir.x, py = coy - x * dir.y, pz = coz - x * dir.z;
     return px * px + py * py + pz * pz <= (double)b.w;
 }
+// RlFlatScene::small_ordered: may the kernel decide ties among the small primitives by scan order alone?
+extern "C" int mirror_small_ordered(void* scene) { return ((MirrorScene*)scene)->flat.small_ordered ? 1 : 0; }
+
 extern "C" void mirror_cull_counts(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first, uint64_t n,
                                    uint64_t* counts) {
     const MirrorScene* ms = (MirrorScene*)scene;

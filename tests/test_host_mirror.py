@@ -269,3 +269,24 @@ def test_prism_cylinders_hold_every_hit_and_are_used_only_where_they_pay():
     d = p - c
     off_axis = np.sqrt(np.maximum((d * d).sum(1) - (d * a).sum(1) ** 2, 0.0))
     assert hit.sum() > 150_000 and (off_axis <= r / 1.04).all(), (off_axis / r).max()   # inside, with the inflation to spare
+
+
+def test_scan_order_may_replace_the_tie_rule_only_where_the_objects_are_ordered():
+    """scene.rs:51 keeps the first object among equal distances.  The kernel's scan of the small primitives (paraboloids, then
+    planes and circles) decides ties by `t < best.t` alone where that order IS the objects' order (RlFlatScene::small_ordered,
+    computed by rl_flatten_scene and handed to the kernel as RlSceneLayout::small_ordered), and by the general rule
+    elsewhere.  The built-in scenes are ordered (app.rs:172-199 lists the paraboloids before the sky lights and the ceiling);
+    the random scenes of the parity tests are not (their planes and circles come first), so both forms of the kernel's loop
+    run under the bit-exact GPU tests -- and a scene with a plane in front of a paraboloid must not be called ordered."""
+    import _random_scene as RS
+    assert M.small_ordered(M.Scene(*M.builtin_desc(0, 0))) and M.small_ordered(M.Scene(*M.builtin_desc(1, 0)))
+    objs, cam = RS.random_scene(3)
+    assert not M.small_ordered(M.Scene(objs, cam))
+    demo, cam = M.builtin_desc(0, 0)
+    kinds = demo["surface_kind"]
+    parab, plane = int(np.flatnonzero(kinds == 3)[0]), int(np.flatnonzero(kinds == 1)[0])
+    swapped = demo.copy()
+    swapped[[parab, plane]] = swapped[[plane, parab]]          # the ceiling now precedes the floor paraboloid
+    assert not M.small_ordered(M.Scene(swapped, cam))
+    only_spheres = demo[kinds == 0]
+    assert M.small_ordered(M.Scene(only_spheres.copy(), cam))   # nothing to order
