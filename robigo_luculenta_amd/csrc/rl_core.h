@@ -438,8 +438,10 @@ RL_HD float rl_rcp_approx(float x) {
 
 // PIPELINED (device): the next plane's records are requested behind this plane's arithmetic (eight more live registers: the
 // plain launches, which have them; the open ones load plane by plane).
-template <bool PIPELINED = true>
-RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
+// PRELOADED (device, with PIPELINED): the caller requested the first plane's two records (pre_n = pr[0], pre_off = pr[1]) itself,
+// ahead of fetching the ray -- the round then starts with one LDS round trip instead of two.
+template <bool PIPELINED = true, bool PRELOADED = false>
+RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pre_n = RlF4(), RlF4 pre_off = RlF4()) {
     const float INF = __builtin_inff();
     float dn[8], ta[8];
     float t_in = -INF, t_out = INF;  // carry the plane number in their low 3 bits
@@ -450,7 +452,10 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out) {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     RlF4 rec_n, rec_off;
-    if (PIPELINED && RL_W_P) rec_n = pr[0], rec_off = pr[1];
+    if (PIPELINED && RL_W_P) {
+        if (PRELOADED) rec_n = pre_n, rec_off = pre_off;
+        else rec_n = pr[0], rec_off = pr[1];
+    }
 #endif
 #if defined(__HIPCC__)
 #pragma unroll

@@ -49,6 +49,9 @@
 #ifndef RL_W_M
 #define RL_W_M 1 // cluster-member rounds: the first member likewise
 #endif
+#ifndef RL_W_PR
+#define RL_W_PR 1 // prism rounds: the first plane's two records likewise
+#endif
 #define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills) in large launches
 
 struct RlSceneLayout {
@@ -154,6 +157,12 @@ __device__ __forceinline__ unsigned long long rl_cycles() {
 // Counters live in (wave-uniform) registers of the wave and reach memory once, when the wave ends: one atomic
 // per event from 4096 waves onto two dozen addresses made the diagnostic build 20x slower than the product.
 #define RL_STAT(K, V) st[K] += (unsigned long long)(V)
+#elif defined(RL_MARK) // region boundaries as comments in the ISA (tools/region_census.py counts the instructions between them; never shipped)
+#define RL_STAT(K, V) do { } while (0)
+#define RL_T0(V) asm volatile("; RL_MARK begin " #V)
+#define RL_T1(K, V) asm volatile("; RL_MARK end " #V)
+#define RL_TACC_PARAM
+#define RL_TACC_ARG
 #else
 #define RL_STAT(K, V) do { } while (0)
 #define RL_T0(V) do { } while (0)
@@ -251,6 +260,25 @@ __device__ __forceinline__ float rl_cull_margin(const RlCullRay& r, RlF4 b, floa
     const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
     return r.q - __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs);
 }
+// the left-hand side of rl_cull_pass's compare (the bound passes iff it is <= r.q)
+__device__ __forceinline__ float rl_cull_lhs(const RlCullRay& r, RlF4 b, float far) {
+    const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
+    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
+    const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
+    return __builtin_fmaf(x, __builtin_fmaf(-2.0f, dd, x), cs);
+}
+// ... with its last FMA spelled out, for the loops that re-load `b` in place between the test and the push: the compiler's
+// two-address form accumulates into b.w and then COPIES the result out of the way of the load (v_mov + v_fmac); the three-address
+// instruction writes it where it can stay
+__device__ __forceinline__ float rl_cull_lhs_apart(const RlCullRay& r, RlF4 b, float far) {
+    const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
+    const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
+    const float x = __builtin_amdgcn_fmed3f(dd, 0.0f, far);
+    const float y = __builtin_fmaf(-2.0f, dd, x);
+    float lhs;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(lhs) : "v"(x), "v"(y), "v"(cs));
+    return lhs;
+}
 __device__ __forceinline__ bool rl_cull_pass(const RlCullRay& r, RlF4 b, float far) {
     const float dd = __builtin_fmaf(r.d.z, b.z, __builtin_fmaf(r.d.y, b.y, __builtin_fmaf(r.d.x, b.x, r.p)));
     const float cs = __builtin_fmaf(r.m.z, b.z, __builtin_fmaf(r.m.y, b.y, __builtin_fmaf(r.m.x, b.x, b.w)));
@@ -323,6 +351,9 @@ __device__ __forceinline__ void rl_fetch_cull_ray(RlWaveScratch* ws, uint32_t ow
 __device__ __forceinline__ void rl_fetch_ray(RlWaveScratch* ws, uint32_t owner, RlF3 dir, RlF3& ro, RlF3& rd) {
     const RlV4 b = ((const RlLdsV4*)&ws->terms_m[0][0])[owner];
     rl_fetch3(owner, dir.x, dir.y, dir.z, rd.x, rd.y, rd.z);
+    // (the slot's fourth word counts as used until the fetch's wait is over: the compiler otherwise hands its register to the next
+    // LDS load of the round and puts an s_waitcnt -- one more exposed round trip -- in front of that load)
+    asm volatile("" : : "v"(b.w));
     ro = rl_f3(b.x * -0.5f, b.y * -0.5f, b.z * -0.5f);
 }
 
@@ -355,7 +386,7 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S>
+template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S, bool SPHERES_IN_LDS>
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, uint32_t small_ordered, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
@@ -372,6 +403,62 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     const uint32_t ws_addr = (uint32_t)(size_t)(RlLdsU32*)ws;
 #define RL_RING_SLOT(RING, M, TAIL) \
     ((RlLdsU32*)(size_t)((ws_addr | (((rl_mbcnt(M) + (TAIL)) << 2) & 0x1fcu)) + (uint32_t)offsetof(RlWaveScratch, RING)))
+    // RL_RING_PUSH: the lanes of mask M (the ballot of a test every lane of the wave ran: exec is all ones here, rl_scan_wave's
+    // contract) write ENTRY to consecutive slots of a ring from TAIL on.  Spelled out because the compiler's form of
+    // `if (pass) *slot = entry` is s_and_saveexec / s_cbranch_execz / ... / s_or exec around the store and re-materialises the
+    // slot mask in a scalar register at every push -- four instructions of a wave's issue for each of the ~35
+    // pushes of an iteration: here the mask becomes exec for the one store, without a branch.
+#ifndef RL_PUSH_ASM
+#define RL_PUSH_ASM 1
+#endif
+#if RL_PUSH_ASM
+#define RL_RING_PUSH(RING, COND, M, TAIL, ENTRY)                                                                        \
+    {                                                                                                                   \
+        uint32_t slot_;                                                                                                 \
+        /* (gfx950: a scalar register written by a vector instruction -- the ballot -- may be read by a vector instruction   \
+           only two wait states later; the compiler does not look into this block, so the block starts with them) */        \
+        asm volatile("s_mov_b64 exec, %6\n\ts_nop 0\n\tv_mbcnt_lo_u32_b32 %0, %1, 0\n\tv_mbcnt_hi_u32_b32 %0, %2, %0\n\t"         \
+                     "v_add_lshl_u32 %0, %0, %3, 2\n\tv_and_or_b32 %0, %0, %4, %5\n\tds_write_b32 %0, %7 offset:%8\n\ts_mov_b64 exec, -1" \
+                     : "=&v"(slot_)                                                                                     \
+                     : "s"((uint32_t)(M)), "s"((uint32_t)((M) >> 32)), "s"(TAIL), "s"(ring_mask), "v"(ws_addr), "s"(M),  \
+                       "v"(ENTRY), "n"(offsetof(RlWaveScratch, RING))                                                   \
+                     : "memory");                                                                                       \
+    }
+#else
+#define RL_RING_PUSH(RING, COND, M, TAIL, ENTRY) if (COND) *RL_RING_SLOT(RING, M, TAIL) = (ENTRY);
+#endif
+    // RL_LE_PUSH: test (LHS <= RHS, the cull's compare) AND push in one: v_cmpx writes the compare's mask to vcc and to exec at
+    // once, the store runs under it, and the ring's tail advances by the mask's population -- one instruction less than a
+    // compare into a scalar pair followed by RL_RING_PUSH and the count.
+#ifndef RL_PUSH_CMPX
+#define RL_PUSH_CMPX 1
+#endif
+#if RL_PUSH_ASM && RL_PUSH_CMPX
+#define RL_LE_PUSH(RING, LHS, RHS, TAIL, ENTRY)                                                                        \
+    {                                                                                                                   \
+        uint32_t slot_, n_;                                                                                             \
+        /* (the count and an s_nop are the two wait states between the compare's write of vcc and the first vector read of it) */ \
+        asm volatile("v_cmpx_le_f32_e32 vcc, %2, %3\n\ts_bcnt1_i32_b64 %1, vcc\n\ts_nop 0\n\t"                              \
+                     "v_mbcnt_lo_u32_b32 %0, vcc_lo, 0\n\tv_mbcnt_hi_u32_b32 %0, vcc_hi, %0\n\t"                            \
+                     "v_add_lshl_u32 %0, %0, %4, 2\n\tv_and_or_b32 %0, %0, %5, %6\n\tds_write_b32 %0, %7 offset:%8\n\t"     \
+                     "s_mov_b64 exec, -1"                                                                               \
+                     : "=&v"(slot_), "=&s"(n_)                                                                           \
+                     : "v"(LHS), "v"(RHS), "s"(TAIL), "s"(ring_mask), "v"(ws_addr), "v"(ENTRY),                          \
+                       "n"(offsetof(RlWaveScratch, RING))                                                               \
+                     : "vcc", "scc", "memory");                                                                         \
+        TAIL += n_;                                                                                                     \
+    }
+#else
+#define RL_LE_PUSH(RING, LHS, RHS, TAIL, ENTRY)                                                                        \
+    {                                                                                                                   \
+        const bool pass_ = (LHS) <= (RHS);                                                                              \
+        const uint64_t m_ = __builtin_amdgcn_ballot_w64(pass_);                                                         \
+        RL_RING_PUSH(RING, pass_, m_, TAIL, ENTRY)                                                                      \
+        TAIL += (uint32_t)__popcll(m_);                                                                                 \
+    }
+#endif
+    uint32_t ring_mask = 0x1fcu;
+    asm volatile("" : "+s"(ring_mask)); // (opaque: one scalar register for the scan instead of an s_movk at every push)
     const RlF4* sph = sv.spheres;
     // The scene's counts are launch constants.  Whatever is derived from them -- "is there any", "how many full groups of
     // four", the member loop's choice -- is loop-invariant over the kernel's persistent loop too, and the optimiser keeps
@@ -445,16 +532,19 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         rl_wave_sync();
         const uint32_t e = ring_b[(b_lim - 64u + lane) & 127u];
         const uint32_t owner = e & 63u;
-        const uint32_t pos = e >> 6;
         // (the record depends on the ring entry alone: its loads are issued ahead of the cross-lane fetch, whose wait then
-        // covers both -- a wave's time is a third waiting for LDS round trips; entries beyond the round are
-        // stale but name records that exist)
+        // covers both -- a wave's time is a third waiting for LDS round trips, DESIGN.md 4.2.  Entries beyond the round are
+        // stale -- an earlier round's, a cylinder round's prism, an emitter batch's tag, or whatever the LDS held when the
+        // kernel started: an LDS read beyond the allocation returns zero, a global one faults, so where the spheres are in
+        // global memory such lanes read record 0)
+        const uint32_t pos = (SPHERES_IN_LDS || lane < count) ? e >> 6 : 0u;
         RlF4 s;
         float s_r2;     // (a clustered sphere's s.w is its cull term)
         uint32_t s_obj;
         if (RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos], s_obj = sv.sphere_obj[pos];
         RlF3 fo, fd;
         rl_fetch_ray(ws, owner, dir, fo, fd);
+        if (RL_W_B) asm volatile("" : : "v"(s.w)); // (a 16-byte LDS load: a 12-byte one takes twice the LDS time)
         const float ox = fo.x, oy = fo.y, oz = fo.z, dx = fd.x, dy = fd.y, dz = fd.z;
         if (lane < count) {
             if (!RL_W_B) s = sph[pos], s_r2 = sv.sphere_r2[pos];
@@ -487,7 +577,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const bool cand = (int)(rl_f2u(q) | (rl_f2u(dd) - 1u) | (DISABLE_BIT)) >= 0;               \
         const uint64_t m = __builtin_amdgcn_ballot_w64(cand);                                       \
         if (m != 0) {                                                                               \
-            if (cand) *RL_RING_SLOT(ring_b, m, b_tail) = ((POS) << 6) | (OWNER);               \
+            RL_RING_PUSH(ring_b, cand, m, b_tail, ((POS) << 6) | (OWNER))               \
             b_tail += (uint32_t)__popcll(m);                                                        \
             if (RL_UNLIKELY(b_tail >= b_lim)) {                                                           \
                 process_spheres(64u);                                                               \
@@ -575,7 +665,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
             const uint32_t j = (n_mine - 1u) - (uint32_t)__builtin_ctz(passed | 0x80000000u); // (a lane with nothing left does not push; ctz(0) is undefined)
-            if (passed != 0u) *RL_RING_SLOT(ring_b, any, b_tail) = ((first + j) << 6) | owner;
+            RL_RING_PUSH(ring_b, passed != 0u, any, b_tail, ((first + j) << 6) | owner)
             b_tail += (uint32_t)__popcll(any);
             passed &= passed - 1u;
             if (RL_UNLIKELY(b_tail >= b_lim)) {
@@ -599,33 +689,28 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #define RL_GROUP_CHILD(J, COUNT, G, ITEM_BASE, PROCESS_A, CYL) RL_GROUP_CHILD_OF(cull[first + (J)], J, COUNT, G, ITEM_BASE, PROCESS_A, CYL)
 #define RL_GROUP_CHILD_OF(BND, J, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                 \
     {                                                                                                   \
-        const RlF4 bnd = (BND);                                                                         \
-        const bool pass = rl_cull_pass(r, bnd, r_far);                                                  \
-        const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                           \
-        { /* (no `if (m != 0)`: some pair of the round passes practically every child) */               \
-            const uint32_t entry = ((first + (J) - (ITEM_BASE)) << 6) | owner;                          \
-            RL_PUSH_##CYL(entry, PROCESS_A)                                                             \
-        }                                                                                               \
+        const float lhs = rl_cull_lhs(r, (BND), r_far);                                                 \
+        /* (no test for an empty mask: some pair of the round passes practically every child) */       \
+        const uint32_t entry = ((first + (J) - (ITEM_BASE)) << 6) | owner;                              \
+        RL_PUSH_##CYL(lhs, entry, PROCESS_A)                                                            \
     }
     /* a child that passed: to ring A ... */                                                            \
-#define RL_PUSH_false(ENTRY, PROCESS_A)                                                                 \
-    if (pass) *RL_RING_SLOT(ring_a, m, a_tail) = (ENTRY);                                        \
-    a_tail += (uint32_t)__popcll(m);                                                                    \
-    if (RL_UNLIKELY(a_tail >= a_lim)) {                                                                       \
+#define RL_PUSH_false(LHS, ENTRY, PROCESS_A)                                                            \
+    RL_LE_PUSH(ring_a, LHS, r.q, a_tail, ENTRY)                                                         \
+    if (RL_UNLIKELY(a_tail >= a_lim)) {                                                                 \
         PROCESS_A(64u);                                                                                 \
-        a_lim += 64u;                                                                                  \
+        a_lim += 64u;                                                                                   \
     }
     /* ... or, a prism of a scene whose prisms carry a second bound, to the cylinder round's ring (process_cylinders) */ \
-#define RL_PUSH_CYL(ENTRY, PROCESS_A)                                                                   \
+#define RL_PUSH_CYL(LHS, ENTRY, PROCESS_A)                                                              \
     if (CYL) {                                                                                          \
-        if (pass) *RL_RING_SLOT(ring_b, m, b_tail) = (ENTRY);                                    \
-        b_tail += (uint32_t)__popcll(m);                                                                \
-        if (RL_UNLIKELY(b_tail >= b_lim)) {                                                                   \
+        RL_LE_PUSH(ring_b, LHS, r.q, b_tail, ENTRY)                                                     \
+        if (RL_UNLIKELY(b_tail >= b_lim)) {                                                             \
             process_cylinders(64u);                                                                     \
-            b_lim += 64u;                                                                              \
+            b_lim += 64u;                                                                               \
         }                                                                                               \
     } else {                                                                                            \
-        RL_PUSH_false(ENTRY, PROCESS_A)                                                                 \
+        RL_PUSH_false(LHS, ENTRY, PROCESS_A)                                                            \
     }
     // The children's loop is unrolled where the scene is staged in LDS (the bounds' addresses become immediates, the loop's
     // counter and branch go: demo +0.8 %, glass +1.6 %, 513 objects +1.1 %; the round handlers inlined behind every child
@@ -653,7 +738,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
         if (UNROLL_S) {                                                                                 \
             _Pragma("unroll") for (uint32_t j = 0; j < 4u; ++j) {                                       \
-                if (j >= (G)) break; /* groups hold 3 or 4 bounds */                                    \
+                if (j >= 3u && j >= (G)) break; /* groups hold 3 or 4 bounds (rl_scene.cpp) */          \
                 if (HOIST_S) RL_GROUP_CHILD_OF(bnd_[j], j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)          \
                 else RL_GROUP_CHILD(j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                             \
             }                                                                                           \
@@ -681,7 +766,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);                                   \
             while (any != 0) {                                                                          \
                 const uint32_t k = (n_here - 1u) - (uint32_t)__builtin_ctz(passed | 0x80000000u);       \
-                if (passed != 0u) *RL_RING_SLOT(ring_s, any, s_tail) = ((c0 + k) << 6) | lane;          \
+                RL_RING_PUSH(ring_s, passed != 0u, any, s_tail, ((c0 + k) << 6) | lane)          \
                 s_tail += (uint32_t)__popcll(any);                                                      \
                 passed &= passed - 1u;                                                                  \
                 if (RL_UNLIKELY(s_tail >= s_lim)) {                                                     \
@@ -702,16 +787,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
         RlF4 g0 = gb[0];                                                                                \
         for (uint32_t g = 0; g < (N_GROUPS); ++g) {                                                     \
-            const bool pass = rl_cull_pass(cr, g0, far);                                                \
-            const uint64_t m = __builtin_amdgcn_ballot_w64(pass);                                       \
+            const float lhs = rl_cull_lhs_apart(cr, g0, far);                                           \
             /* the next bound goes into the registers this one has just left (the table has slack at its end): loaded one   \
                test ahead into registers of its own it had to be COPIED over g0 every time round -- four moves and an address \
                per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
             g0 = gb[g + 1];                                                                             \
             /* (no `if (m != 0)` around the push: with 64 rays per wave some lane passes practically every group bound, and the   \
                test would be one more instruction per group) */                                         \
-            if (pass) *RL_RING_SLOT(ring_s, m, s_tail) = (g << 6) | lane; /* group number within its kind */ \
-            s_tail += (uint32_t)__popcll(m);                                                            \
+            RL_LE_PUSH(ring_s, lhs, cr.q, s_tail, (g << 6) | lane) /* group number within its kind */    \
             if (RL_UNLIKELY(s_tail >= s_lim)) {                                                         \
                 RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                       \
                 s_lim += 64u;                                                                           \
@@ -753,14 +836,19 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         uint32_t e = ring_a[(a_lim - 64u + lane) & 127u];
         uint32_t owner = e & 63u;
         const uint32_t prism = e >> 6;
+        const RlF4* pr = sv.prisms + __umul24((uint32_t)RL_PRISM_STRIDE, lane < count ? prism : 0u);
+        // (the plain launches of a scene whose prisms are staged in LDS: the first plane's records depend on the ring entry alone
+        // and are requested ahead of the cross-lane fetch, whose wait covers them)
+        constexpr bool PRE = HOIST_S && SPLIT && RL_W_PR;
+        RlF4 pre_n = RlF4(), pre_off = RlF4();
+        if (PRE) pre_n = pr[0], pre_off = pr[1];
         RlF3 ro, rd;
         rl_fetch_ray(ws, owner, dir, ro, rd);
         // The shortcut of rl_core.h decides all but ~0.1 % of the pairs (near an edge, grazing, within rounding of a face);
         // a round that holds one of those evaluates the reference's Compound tree instead -- for every lane, the branch is
         // wave-uniform, and with the same result for the lanes the shortcut had decided.
-        const RlF4* pr = sv.prisms + __umul24((uint32_t)RL_PRISM_STRIDE, lane < count ? prism : 0u);
         RlCand c;
-        int status = rl_hex_prism_fast<HOIST_S && SPLIT>(pr, ro, rd, &c); // (the plain launches of a scene whose prisms are staged in LDS)
+        int status = rl_hex_prism_fast<HOIST_S && SPLIT, PRE>(pr, ro, rd, &c, pre_n, pre_off);
         if (lane >= count) status = RL_PRISM_MISS;
         if (__builtin_amdgcn_ballot_w64(status == RL_PRISM_UNSURE) != 0) {
             RL_STAT(RL_ST_P_SLOW, 1);
@@ -805,7 +893,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const bool pass = lane < count && rl_cyl_pass(r, cy0, rl_xyz(cy1));
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
-            if (pass) *RL_RING_SLOT(ring_a, m, a_tail) = e;
+            RL_RING_PUSH(ring_a, pass, m, a_tail, e)
             a_tail += (uint32_t)__popcll(m);
             if (RL_UNLIKELY(a_tail >= a_lim)) {
                 process_prisms(64u);
@@ -825,6 +913,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #undef RL_PUSH_CYL
 #undef RL_PUSH_false
 #undef RL_RING_SLOT
+#undef RL_RING_PUSH
+#undef RL_LE_PUSH
     if (CYL && b_tail != b_lim - 64u) {
         process_cylinders(b_tail - (b_lim - 64u));
         b_lim = b_tail + 64u;
@@ -1354,7 +1444,9 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         }
         // (ring-S rounds unrolled wherever the cull table is in LDS -- except in the fused open launches of a tables-only scene, the
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(FUSED && OPEN) && RL_W_S>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        // (... and their children's bounds requested ahead of the fetch wherever that leaves the instantiation spill-free: not in the
+        // open launches of a tables-only scene, 64-bit global addresses again)
+        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) && RL_W_S, STAGE == RL_STAGE_ALL>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {

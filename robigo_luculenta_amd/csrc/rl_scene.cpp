@@ -943,6 +943,7 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
                 improve_partition(balls, clusters, k);
             }
 #ifdef RL_GROUP_GC
+            static_assert(RL_GROUP_GC == 3 || RL_GROUP_GC == 4, "the kernel's unrolled ring-S rounds test three bounds of a group unconditionally and a fourth if there is one");
             for (uint32_t g : {(uint32_t)RL_GROUP_GC}) {
 #else
             for (uint32_t g : {3u, 4u}) {
