@@ -437,6 +437,15 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.cull_cmax2 = fs.cull_cmax2;
     // ... then the per-object arrays
     lay.off_objects = append(fs.objects);
+    // (on the device an object's group bits are the blob index of the record its hit is completed from, RlSceneView::records)
+    for (size_t i = 0; i < fs.objects.size(); ++i) {
+        const uint32_t bits = rl_f2u(fs.objects[i].w), kind = rl_object_surface(bits), group = rl_object_group(bits);
+        const uint32_t index = kind == RL_SURFACE_SPHERE       ? group
+                               : kind == RL_SURFACE_PARABOLOID ? lay.off_parabs + 3u * group
+                               : kind == RL_SURFACE_HEX_PRISM  ? lay.off_prisms + (uint32_t)RL_PRISM_STRIDE * group
+                                                               : lay.off_planes + 2u * group;
+        blob[lay.off_objects + i].w = rl_u2f(rl_object_bits(kind, rl_object_material(bits), index));
+    }
     lay.off_cie = (uint32_t)blob.size();
     const RlF4* cie = (const RlF4*)RL_CIE1931_XYZ0;
     blob.insert(blob.end(), cie, cie + RL_CIE_SAMPLES);

@@ -648,6 +648,33 @@ RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit
                             uint32_t group_index) {
     RlIsect is;
     is.position = rl_add(o, rl_mul(dir, hit.t));
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The device's form: ONE record load whatever the surface is (`group_index` is a blob index here, RlSceneView::records; hit.sub
+    // is zero unless the hit is a prism's), selects instead of a branch per kind -- as an if / else-if chain the compiler built a
+    // tree of exec-mask branches with copies at every join, ~45 scalar instructions and a dozen moves per bounce, and a wave's
+    // time goes into issuing instructions whatever their kind.  Same operations on the same values as below.
+    {
+        const RlF4 rec4 = sv.records[group_index + 2u * hit.sub];
+        asm volatile("" : : "v"(rec4.w)); // (a 16-byte load: a 12-byte LDS read takes twice the LDS time)
+        const RlF3 rec = rl_xyz(rec4);
+        RlF3 curved = rl_sub(is.position, rec); // sphere: position - centre; paraboloid: local_pos
+        if (surface_kind == RL_SURFACE_PARABOLOID) {
+            const RlF3 normal = rl_xyz(sv.records[group_index + 1u]);
+            const RlF3 focal_point = rl_xyz(sv.records[group_index + 2u]);
+            const RlF3 plane_pr = rl_sub(curved, rl_mul(normal, rl_dot(curved, normal)));
+            curved = rl_sub(focal_point, plane_pr);
+        }
+        // plane, circle: two-sided (the normal that faces the ray); prism: one-sided, as stored
+        const bool flip = ((surface_kind == RL_SURFACE_PLANE) | (surface_kind == RL_SURFACE_CIRCLE)) & !(rl_dot(rec, dir) < 0.0f);
+        const uint32_t sign = flip ? 0x80000000u : 0u;
+        const RlF3 flat = rl_f3(rl_u2f(rl_f2u(rec.x) ^ sign), rl_u2f(rl_f2u(rec.y) ^ sign), rl_u2f(rl_f2u(rec.z) ^ sign));
+        // (every lane normalises: the lanes of a flat surface a vector nobody reads)
+        const RlF3 unit = rl_normalise(curved);
+        const bool is_curved = (surface_kind == RL_SURFACE_SPHERE) | (surface_kind == RL_SURFACE_PARABOLOID);
+        is.normal = rl_f3(is_curved ? unit.x : flat.x, is_curved ? unit.y : flat.y, is_curved ? unit.z : flat.z);
+        return is;
+    }
+#endif
     is.normal = rl_f3(0.0f, 0.0f, 0.0f);
     RlF3 curved = rl_f3(0.0f, 0.0f, 0.0f);
     if (surface_kind == RL_SURFACE_SPHERE) {

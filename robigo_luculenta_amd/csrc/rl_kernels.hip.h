@@ -994,6 +994,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     sv.n_prisms = lay.n_prisms;
     sv.n_objects = lay.n_objects;
     sv.camera_rec = base + (lay.off_camera - tab0);
+    sv.records = big; // (a tables-only stage completes its hits from the blob in global memory, like its spheres)
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
     typedef __attribute__((address_space(3))) float RlLdsF32;

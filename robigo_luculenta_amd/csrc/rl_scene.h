@@ -78,6 +78,10 @@ struct RlSceneView {
     // (camera.rs:56, constant per scene).  Read from memory where a path starts instead of being held
     // in a dozen scalar registers across the whole persistent loop.
     const RlF4* camera_rec;
+    // Device only: the blob every record array above lives in.  On the device an object's "group" bits hold the blob index of the
+    // record its hit is completed from -- the sphere's record, the plane's / circle's normal, the paraboloid's first, the prism's
+    // first -- so that rl_finish_hit reads it with one load whatever the surface is (rl_api.hip: rl_scene_create writes them).
+    const RlF4* records;
 };
 
 // Host-side flattened scene (built once by rl_scene_create).
