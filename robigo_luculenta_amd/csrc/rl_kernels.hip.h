@@ -625,7 +625,11 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         // them, the flush at the end of the sphere pass -- gives every pair two lanes, each with half of the members: half the
         // loop for the same round.
         const uint32_t n_members = cluster_k; // wave-uniform, <= RL_CLUSTER_K_MAX
+#ifdef RL_CLUSTER_K
         const bool split = SPLIT && count <= 32u && (n_members == 10u || n_members == 14u);
+#else
+        const bool split = SPLIT && count <= 32u;
+#endif
         const uint32_t slot = split ? (lane & 31u) : lane;
         const uint32_t e = ring_a[(a_lim - 64u + slot) & 127u];
         const uint32_t owner = e & 63u;
@@ -656,11 +660,19 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             passed = slot < count ? ~failed & ((1u << (N)) - 1u) : 0u; /* lanes beyond the round hold stale pairs (whose ray may have ended: NaN margins) */ \
             n_mine = (N);                                                                                                \
         }
+#ifdef RL_CLUSTER_K // (a build that forces a cluster size, A/B: any size)
         if (n_members == 10u) {
             if (split) RL_MEMBERS(5u) else RL_MEMBERS(10u)
         } else if (n_members == 14u) {
             if (split) RL_MEMBERS(7u) else RL_MEMBERS(14u)
         } else RL_MEMBERS(n_members)
+#else // RL_CLUSTER_K_CHOICES: one compare decides (the three-way form was a tree of six scalar instructions per round)
+        if (n_members == 10u) {
+            if (split) RL_MEMBERS(5u) else RL_MEMBERS(10u)
+        } else {
+            if (split) RL_MEMBERS(7u) else RL_MEMBERS(14u)
+        }
+#endif
 #undef RL_MEMBERS
         uint64_t any = __builtin_amdgcn_ballot_w64(passed != 0u);
         while (any != 0) {
@@ -786,15 +798,17 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     {                                                                                                   \
         const RlF4* gb = cull + n_level1 + (FIRST_GROUP);                                               \
         RlF4 g0 = gb[0];                                                                                \
-        for (uint32_t g = 0; g < (N_GROUPS); ++g) {                                                     \
+        uint32_t g_entry = lane; /* (g << 6) | lane, kept running: one v_add per group instead of a shift-or from a scalar */ \
+        for (const RlF4* const g_end = gb + (N_GROUPS); gb != g_end;) {                                 \
             const float lhs = rl_cull_lhs_apart(cr, g0, far);                                           \
             /* the next bound goes into the registers this one has just left (the table has slack at its end): loaded one   \
                test ahead into registers of its own it had to be COPIED over g0 every time round -- four moves and an address \
                per eleven-instruction test; the push below and the other waves cover the load (demo +1.0 %, glass +2 %) */  \
-            g0 = gb[g + 1];                                                                             \
+            g0 = *++gb;                                                                                 \
             /* (no `if (m != 0)` around the push: with 64 rays per wave some lane passes practically every group bound, and the   \
                test would be one more instruction per group) */                                         \
-            RL_LE_PUSH(ring_s, lhs, cr.q, s_tail, (g << 6) | lane) /* group number within its kind */    \
+            RL_LE_PUSH(ring_s, lhs, cr.q, s_tail, g_entry) /* group number within its kind */            \
+            g_entry += 64u;                                                                             \
             if (RL_UNLIKELY(s_tail >= s_lim)) {                                                         \
                 RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                       \
                 s_lim += 64u;                                                                           \
