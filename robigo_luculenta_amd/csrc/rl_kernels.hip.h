@@ -1239,12 +1239,13 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
 #endif
         // ---- hand new paths to the lanes whose path ended (trace_unit.rs:152-167) ----
         RL_T0(t_refill);
-        for (;;) {
-            const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
-            if (need == 0) break;
-            const uint32_t avail = stash_count - stash_head;
-            if (avail == 0) {
-                if (drained) break;
+        // Two steps, written straight-line (at most: refill, hand out, and -- when more lanes asked than the stash held -- once
+        // more): as a loop the compiler kept the path's sixteen registers in loop-carried copies and moved all of them at the end of
+        // every hand-out (16 v_mov per iteration); a lane that still has no path after the second hand-out -- the tail of a launch --
+        // asks again in the next iteration.
+        // refill(): all 64 lanes generate one camera ray each (full exec mask) into the stash; false if there are no paths to take.
+        auto refill = [&]() -> bool {
+            if (drained) return false;
                 // Refill: all 64 lanes generate one camera ray each (full exec mask) into the stash.
                 uint32_t open_n = 0; // OPEN: size of the job the refill comes from
                 if (OPEN) {
@@ -1369,7 +1370,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                             __hip_atomic_store(&od->closing, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
-                    if (!got) break; // no paths to hand out right now (or ever again, if drained)
+                    if (!got) return false; // no paths to hand out right now (or ever again, if drained)
                 }
                 if (!OPEN && chunk_next == chunk_end) {
                     // Small launches (fewer than 16 paths per lane of the grid: the reference's 524,288-path
@@ -1411,8 +1412,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 stash_head = 0;
                 stash_count = 64;
                 if (!OPEN && chunk_next >= job.n_paths) drained = true;
-                continue;
-            }
+            return true;
+        };
+        // hand_out(need): the lanes of `need` (no path) take the stash's next slots; true if every one of them was served a slot.
+        auto hand_out = [&](const uint64_t need) -> bool {
+            const uint32_t avail = stash_count - stash_head;
             const uint32_t rank = rl_mbcnt(need);
             const uint32_t slot = stash_head + rank;
             // One condition, combined without branches, and selects instead of assignments under it: with the sixteen assignments
@@ -1438,9 +1442,17 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             }
             const uint32_t wanted = (uint32_t)__popcll(need);
             stash_head += wanted < avail ? wanted : avail;
-            // (the common case leaves here instead of through a second pass of the loop's head: every lane that asked was given a
-            // slot -- one without a path, at the tail of a launch, asks again in the next iteration)
-            if (RL_LIKELY(wanted <= avail)) break;
+            return wanted <= avail;
+        };
+        {
+            const uint64_t need = __builtin_amdgcn_ballot_w64(!active);
+            if (need != 0) { // (one call site for refill(): it holds the camera's code)
+                bool served = false;
+                if (RL_LIKELY(stash_count != stash_head)) served = hand_out(need);
+                if (RL_UNLIKELY(!served)) {
+                    if (refill()) hand_out(__builtin_amdgcn_ballot_w64(!active));
+                }
+            }
         }
         RL_T1(RL_ST_T_REFILL, t_refill);
         if (__builtin_amdgcn_ballot_w64(active) == 0) {
