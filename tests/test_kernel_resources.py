@@ -95,3 +95,24 @@ def test_open_variants_wait_for_their_results_before_counting_them(usage):
     for name, (is_open, body) in bodies.items():
         n = len(re.findall(r"s_waitcnt vmcnt\(0\) ; rl_settle", body))
         assert (n >= 1) if is_open else (n == 0), (name, n)   # (the compiler may merge settle()'s call sites into one)
+
+
+def test_ring_pushes_keep_their_wait_states_and_restore_exec(usage):
+    """The ring pushes of rl_scan_wave are inline assembly (RL_RING_PUSH / RL_LE_PUSH: the pass mask becomes exec for the one
+    store).  The compiler's hazard recogniser does not look into such blocks, so they carry their own wait states: gfx950
+    wants two between a vector instruction's write of a scalar register (the ballot, v_cmpx's vcc) and the first vector read
+    of it -- without them v_mbcnt reads a stale mask, the ring gets garbage slots and the photons differ (seen on the device
+    in round 5 before the s_nop went in).  Every block must also leave exec all ones again."""
+    text = usage["__asm__"]
+    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, re.S)
+    pushes = [b for b in blocks if "ds_write_b32" in b and "exec" in b]
+    assert len(pushes) > 24 * 10   # every instantiation, every push site
+    for b in pushes:
+        lines = [l.strip() for l in b.strip().splitlines()]
+        assert lines[-1] == "s_mov_b64 exec, -1", b
+        if lines[0].startswith("v_cmpx_le_f32"):    # RL_LE_PUSH: count + s_nop between the compare and the first v_mbcnt
+            assert lines[1].startswith("s_bcnt1_i32_b64") and lines[1].endswith("vcc") and lines[2].startswith("s_nop"), b
+            assert lines[3].startswith("v_mbcnt_lo_u32_b32") and "vcc_lo" in lines[3], b
+        else:                                         # RL_RING_PUSH: exec from the mask, then an s_nop, then v_mbcnt
+            assert lines[0].startswith("s_mov_b64 exec, s[") and lines[1].startswith("s_nop"), b
+            assert lines[2].startswith("v_mbcnt_lo_u32_b32"), b
