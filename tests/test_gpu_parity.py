@@ -463,6 +463,47 @@ def test_scene_too_large_for_lds_spills_to_global_fetch():
     assert sum(ran[16:]) >= 1 and sum(ran[:16]) == 0, ran       # an instantiation that stages the tables only, although the unit asked for LDS
 
 
+def _poison_lds(pattern):
+    """tests/lds_poison: every CU's LDS filled with `pattern` (test infrastructure, built by __graft_entry__.build())."""
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lds_poison", "_build", "liblds_poison.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.dirname(os.path.dirname(so))], check=True)
+    lib = C.CDLL(so)
+    lib.lds_poison.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+    rc = lib.lds_poison(0, pattern, 2048)
+    assert rc == 0, rc
+
+
+@pytest.mark.parametrize("pattern", [0xFFFFFFFF, 0x7FC00000, 0x00ABCDEF])
+def test_stale_ring_slots_are_never_loaded_through(pattern):
+    """A round of fewer than 64 pairs reads 64 ring slots; the slots beyond the round hold whatever was there -- at the start of a
+    kernel, whatever the previous kernel left in LDS.  Their lanes must be pointed at record 0 before anything is loaded through
+    them: from LDS a wild index reads zero, from global memory it faults (round 5: the sphere tails of the global-fetch
+    variants loaded `spheres[stale >> 6]` unconditionally for a few builds -- found only because the LDS happened to hold
+    scene floats).  Here the LDS is filled with a pattern first, then every fetch mode renders few paths (few waves, partial
+    rounds everywhere) and must still equal the oracle: built-in scene from LDS and from global memory, and a scene too large
+    for LDS (tables staged, spheres from global memory), un-fused plain and open launches."""
+    W, H, N = 320, 180, 1 << 12
+    for which, param, fetches in [(R.SCENE_DEMO, 0, (R.FETCH_GLOBAL, R.FETCH_LDS)), (R.SCENE_GLASS_STRESS, 0, (R.FETCH_GLOBAL,)),
+                                  (R.SCENE_DEMO, 1500, (R.FETCH_LDS,))]:
+        objs, cam = R.builtin_scene_desc(which, param)
+        scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+        want, segs = oscene.render(W, H, 4, 2, 77, N, threads=8)
+        for fetch in fetches:
+            for blocking in (True, False):
+                t = R.TraceUnit(0, W, H, n_photons=N)
+                t.set_fetch(fetch)
+                _poison_lds(pattern)
+                if blocking:
+                    t.render(scene, seed=4, stream=2, first_path_index=77)          # an open launch
+                else:
+                    t.render_async(scene, seed=4, stream=2, first_path_index=77)    # a plain launch
+                    t.sync()
+                assert t.mapped_photons.tobytes() == want.tobytes(), (which, param, fetch, blocking)
+                assert t.stats()[1] == segs
+
+
 _TABLES_SCENES = {}
 
 
