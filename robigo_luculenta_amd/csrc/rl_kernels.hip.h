@@ -24,7 +24,10 @@
 //     two, a taken branch two), a third waiting for LDS round trips (an exposed one costs ten instructions, a ds_bpermute_b32
 //     five) and a fifth issue-stalled.  Hence: record loads issued ahead of the data they are used with, the rays' cull terms
 //     gathered from LDS slots instead of permuted across lanes, conditions combined without branches, ring pushes in four
-//     vector instructions -- and no attention to lane occupancy for its own sake;
+//     vector instructions -- and no attention to lane occupancy for its own sake.  The second half of round 5 read the compiled
+//     kernel region by region (-DRL_MARK, tools/region_census.py) for what the source does not say: the pushes' exec dance (now
+//     eight instructions of inline assembly, RL_RING_PUSH / RL_LE_PUSH), an exec-mask tree for an if / else-if chain
+//     (rl_finish_hit: one load and selects), sixteen copies at a loop's back edge (the stash hand-out: straight-line now);
 //   * OPEN variant: the kernel stays resident and takes the paths of blocking render calls from a job table the host
 //     appends to while it runs (RlOpenDev / RlOpenCtl below): rl_trace_kernel_open, at most 120 VGPRs so that the small
 //     kernels of the other units run beside it (the plain launches, rl_trace_kernel, may use all 128).
