@@ -35,6 +35,9 @@ BATCH = 1024 * 512  # trace_unit.rs:67
 # (SURVEY 8d): sphere 19, paraboloid 38, plane / circle / half-space 14.
 FLOPS_SPHERE, FLOPS_PARABOLOID, FLOPS_PLANE = 19, 38, 14
 PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)"
+# 256 CUs x 4 SIMDs x 64 lanes per wave64 instruction / 2 cycles x 2.4 GHz: VALU lane-operations per second (an FMA counts once)
+PEAK_VALU_TLANEOPS = 256 * 4 * 64 / 2 * 2.4e9 / 1e12   # 78.6
+PLAIN_STREAM_CYCLES_AT_4_WAVES = 2.6
 
 CONFIGS = {
     # name: (scene, param, width, height)
@@ -179,16 +182,37 @@ def scene_of(R, config):
 
 def chip_shape():
     """(CUs, SIMDs, XCDs) of the device the counters were collected on: the CU count from the device's properties (four SIMDs
-    per CU on CDNA), eight XCDs on MI300-class parts unless the counter files say otherwise (executed_live counts the
-    GRBM_GUI_ACTIVE instances).  ADVICE r04: not hard-coded at the use."""
-    cus = 256
+    per CU on CDNA), the XCD count from the KFD topology (num_xcc; eight on MI300-class parts when that cannot be read) unless the counter files say
+    otherwise (executed_live counts the GRBM_GUI_ACTIVE instances).  ADVICE r04 / r05: not hard-coded."""
+    cus, xcds = 256, 8
     try:
         import torch
         if torch.cuda.is_available():
             cus = int(torch.cuda.get_device_properties(0).multi_processor_count)
     except Exception:   # noqa: BLE001 -- no torch, no device: the MI355X figures
         pass
-    return cus, 4 * cus, 8
+    try:   # (ADVICE r05: the XCD count from the driver's topology -- num_xcc of the first GPU node -- not a literal)
+        for node in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+            props = dict(l.split()[:2] for l in open(node).read().splitlines() if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0 and int(props.get("num_xcc", "0")) > 0:
+                xcds = int(props["num_xcc"])
+                break
+    except (OSError, ValueError):
+        pass
+    return cus, 4 * cus, xcds
+
+
+def issue_ceiling(executed):
+    """The kernel's cycles per vector instruction per SIMD beside the wall-clock rate of a plain stream of independent f32 vector
+    instructions at the same occupancy (tools/valu_microbench.hip, `wall c/i` at 4 waves per SIMD: 2.51-2.73 over the instruction
+    kinds and rounds measured, profiles/r0*_valu_microbench.txt): what this chip issues in practice, against the nominal 2."""
+    cyc = (executed or {}).get("cycles_per_valu_inst_per_simd")
+    plain = {"cycles_per_valu_inst_plain_stream": PLAIN_STREAM_CYCLES_AT_4_WAVES, "valu_busy_ceiling": 2.0 / PLAIN_STREAM_CYCLES_AT_4_WAVES,
+             "source": "tools/valu_microbench.hip wall-clock column at 4 waves per SIMD (profiles/r05_valu_microbench.txt: 2.51-2.73)"}
+    if cyc:
+        plain["kernel_cycles_per_valu_inst"] = cyc
+        plain["kernel_vs_plain_stream"] = PLAIN_STREAM_CYCLES_AT_4_WAVES / cyc   # 1.0 = the kernel's vector instructions issue as fast as a plain stream's
+    return plain
 
 
 def executed_from_profile(R, config, fetch, rays_per_launch, launch_ms, paths_per_launch=None):
@@ -727,15 +751,28 @@ def main():
                 "share_of_step": exchange_ms / (elapsed / args.steps * 1e3),
                 "kernel_share_of_step": (sum_kernel_ms / world) / (elapsed * 1e3)},
             "scaling_detail": None if world == 1 else scaling_detail(world, scaling, total_rays / elapsed / 1e6, n1, other),
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                         # what the hardware did, first (profiles/*_pmc.json of this build; None when that profile is stale):
-                         "frac_executed": executed.get("useful_lane_slots_vs_2cyc"),   # VALU lane-slots used / lane-slots at one wave64 instruction per 2 cycles per SIMD
+            # `frac` is a UTILISATION -- the share of the vector ALU's lane-slots the kernel executed, from the
+            # counters (this run's own rocprofv3 passes when they ran, else the committed profile of this build) -- and
+            # achieved / peak are that same quantity in lane-operations per second.  The reference-flops figure of rounds 1-5
+            # (> 1 because the kernel culls most of the reference's linear scan) is kept as `algorithmic`, labelled as a speed-up.
+            "roofline": {"bound": "valu", "unit": "Tlane-op/s", "peak": PEAK_VALU_TLANEOPS,
+                         "achieved": (executed.get("useful_lane_slots_vs_2cyc") or 0.0) * PEAK_VALU_TLANEOPS if executed.get("useful_lane_slots_vs_2cyc") else None,
+                         "frac": executed.get("useful_lane_slots_vs_2cyc"),
+                         "frac_source": None if executed.get("stale") else executed.get("profile"),
+                         "frac_is": "UTILISATION: VALU lane-slots executed (SQ_THREAD_CYCLES_VALU) / lane-slots the chip offers at one wave64 "
+                                    "instruction per 2 cycles per SIMD over the kernel's cycles = valu_busy x active lanes; from the counters",
+                         "frac_executed": executed.get("useful_lane_slots_vs_2cyc"),   # (the name rounds 3-5 reported it under)
                          "valu_busy": executed.get("issue_frac_vs_2cyc"),              # VALU instructions issued / issue slots at that rate
-                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
-                         "frac_is": "ALGORITHMIC: the reference's linear-scan flops per ray (SURVEY 8d) x rays / kernel time, over the "
-                                    "FP32-vector peak.  The kernel culls most of that scan, so this is a speed-up-over-linear-scan "
-                                    "figure, not a utilisation; frac_executed / valu_busy (details in `executed`) are what the hardware did",
-                         "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
+                         # how far the kernel's vector issue rate is from what this chip issues IN PRACTICE at the kernel's occupancy:
+                         # tools/valu_microbench.hip, wall-clock cycles per wave64 instruction per SIMD of a plain independent stream
+                         "issue_ceiling": issue_ceiling(executed),
+                         "algorithmic": {"achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                                         "frac_of_unpacked_fp32_peak": achieved / (PEAK_FP32_VECTOR_TFLOPS / 2),  # 78.6 TFLOP/s, SURVEY 8(d)
+                                         "is": "SPEED-UP over the reference's linear scan, not a utilisation: the reference's reject-path flops per "
+                                               "ray (SURVEY 8d) x rays / kernel time over the FP32-vector peak; above 1 because the kernel culls most of that scan "
+                                               "(bit-identical photons and segment counts)"},
+                         "frac_algorithmic": achieved / PEAK_FP32_VECTOR_TFLOPS,
                          "kernel": "rl_trace_kernel", "kernel_ms_per_launch": launch_ms, "rays_per_launch": rays_per_launch,
                          "algorithmic_flops_per_ray": f_seg,
                          "executed": executed,
@@ -758,8 +795,13 @@ def main():
         if world == 1 and not args.no_live_counters and not os.environ.get("RL_BENCH_LIVE_CHILD"):
             live = executed_live(args, executed)
             out["roofline"]["executed_live"] = live
-            if not live.get("skipped") and executed.get("stale"):   # no committed profile of this build: the live counters lead
-                out["roofline"]["frac_executed"], out["roofline"]["valu_busy"] = live["useful_lane_slots_vs_2cyc"], live["issue_frac_vs_2cyc"]
+            if not live.get("skipped"):   # counted in THIS run: the live counters lead, the committed profile is the cross-check
+                rf = out["roofline"]
+                rf["frac"] = rf["frac_executed"] = live["useful_lane_slots_vs_2cyc"]
+                rf["valu_busy"] = live["issue_frac_vs_2cyc"]
+                rf["achieved"] = rf["frac"] * PEAK_VALU_TLANEOPS
+                rf["frac_source"] = "executed_live (rocprofv3 --pmc passes of this run)"
+                rf["issue_ceiling"] = issue_ceiling(live)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(R, objs, cam, W, H)
         print(json.dumps(out), flush=True)

@@ -15,6 +15,11 @@ extern "C" {
  * intensity), i < m = n / 3, result 1 or 0 in y[i], 11 vector3.rs:56-67 normalise of the triples (x[i], x[m+i], x[2m+i])
  * into (y[i], y[m+i], y[2m+i]). */
 int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n);
+/* The short square root / reciprocal / division by 200 of csrc/rl_math.h and rl_core.h (fn 16, 17, 18 of rl_debug_math_probe)
+ * against the compiler's correctly rounded expansions, ON THE DEVICE, for every float whose bits lie in [lo_bits, hi_bits) -- and
+ * its negative when both_signs != 0.  counts[0] = arguments whose results differ, counts[1] = arguments compared, *example = the
+ * bits of one argument that differs.  Seconds for the whole normal range: the exhaustive checks of the -m gpu suite. */
+int rl_debug_math_sweep(int device, int fn, uint32_t lo_bits, uint32_t hi_bits, int both_signs, uint64_t* counts, uint32_t* example);
 /* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
  * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
 int rl_debug_batch_histogram(int device, uint64_t* out);

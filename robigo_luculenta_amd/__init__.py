@@ -416,6 +416,16 @@ def math_probe(fn, x, device=0):
     return y
 
 
+def math_sweep(fn, lo_bits, hi_bits, both_signs=False, device=0):
+    """rl_debug_math_sweep: the short form `fn` ("sqrt_short", "recip_short", "div200_short") against the compiler's IEEE expansion
+    on the device for every float with bits in [lo_bits, hi_bits) (and its negative): (mismatches, compared, example bits)."""
+    counts = (C.c_uint64 * 2)()
+    example = C.c_uint32(0)
+    check(lib.rl_debug_math_sweep(device, {"sqrt_short": 16, "recip_short": 17, "div200_short": 18}[fn], int(lo_bits), int(hi_bits),
+                                  1 if both_signs else 0, counts, C.byref(example)))
+    return int(counts[0]), int(counts[1]), int(example.value)
+
+
 def prism_probe(scene, prism, rays):
     """rl_debug_prism_probe: the prism shortcut (rl_hex_prism_fast) and the Compound tree, both on the GPU, for `rays`
     (n x 6: origin, direction) against prism number `prism` of the scene's flattened order.  Returns an (n, 5) uint32

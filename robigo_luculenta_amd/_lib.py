@@ -131,6 +131,7 @@ SIGNATURES = {
 # include/robigo_luculenta_debug.h: diagnostics, not part of the drop-in boundary
 DEBUG_SIGNATURES = {
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
+    "rl_debug_math_sweep": (_i, [_i, _i, _u32, _u32, _i, _vp, _vp]),
     "rl_debug_batch_histogram": (_i, [_i, _vp]),
     "rl_debug_variant_launches": (_i, [_vp]),
     "rl_debug_prism_probe": (_i, [_vp, _u32, _vp, _u32, _vp]),

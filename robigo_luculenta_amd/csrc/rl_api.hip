@@ -437,6 +437,14 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.cull_cmax2 = fs.cull_cmax2;
     // ... then the per-object arrays
     lay.off_objects = append(fs.objects);
+    // (an object's group bits hold 26 bits -- a blob index on the device -- and rl_object_bits masks silently)
+    if (blob.size() >= (1u << 26) || fs.cluster_base + fs.spheres.size() >= (1u << 26))
+        return fail(RL_E_INVALID, "scene too large: its records do not fit the 26 index bits of an object record");
+    if (fs.n_clusters != 0 && fs.cluster_k != 10u && fs.cluster_k != 14u) {
+#ifndef RL_CLUSTER_K
+        return fail(RL_E_INVALID, "cluster size is not one the trace kernel's member rounds are unrolled for (RL_CLUSTER_K_CHOICES)");
+#endif
+    }
     // (on the device an object's group bits are the blob index of the record its hit is completed from, RlSceneView::records)
     for (size_t i = 0; i < fs.objects.size(); ++i) {
         const uint32_t bits = rl_f2u(fs.objects[i].w), kind = rl_object_surface(bits), group = rl_object_group(bits);
@@ -1714,6 +1722,30 @@ int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n
     (void)hipFree(dx);
     if (dy) (void)hipFree(dy);
     if (e != hipSuccess) return fail(RL_E_HIP, std::string("math probe: ") + hipGetErrorString(e));
+    return RL_OK;
+}
+
+// The short forms (fn 16 rl_sqrtf, 17 rl_recipf, 18 rl_div200f) against the compiler's IEEE expansions for every float with bits in
+// [lo_bits, hi_bits) -- and its negative when both_signs -- on the device.  counts[0] = arguments that differ, counts[1] = arguments
+// compared; *example = one argument that differs (bits), if any.
+int rl_debug_math_sweep(int device, int fn, uint32_t lo_bits, uint32_t hi_bits, int both_signs, uint64_t* counts, uint32_t* example) {
+    if (!counts || !example || fn < 16 || fn > 18 || hi_bits <= lo_bits) return fail(RL_E_INVALID, "math sweep: fn 16..18, lo < hi");
+    int rc = use_device(device);
+    if (rc != RL_OK) return rc;
+    unsigned long long* bad = nullptr;
+    RL_HIP(hipMalloc((void**)&bad, 32));
+    hipError_t e = hipMemset(bad, 0, 32);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rl_math_sweep_kernel, dim3(8192), dim3(RL_BLOCK), 0, 0, fn, lo_bits, hi_bits, both_signs, bad, (uint32_t*)(bad + 2));
+        e = hipGetLastError();
+    }
+    unsigned long long host[4] = {0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(host, bad, 32, hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return fail(RL_E_HIP, std::string("math sweep: ") + hipGetErrorString(e));
+    counts[0] = host[0];
+    counts[1] = host[1];
+    *example = (uint32_t)host[2];
     return RL_OK;
 }
 

@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include <cerrno>
 #include <fcntl.h>  // open(O_DIRECTORY): the fsync of a directory behind a rename
 #include <unistd.h> // fsync
 
@@ -190,11 +191,17 @@ int replace_file(const std::string& tmp, const std::string& path) {
     if (std::rename(tmp.c_str(), path.c_str()) != 0) return RL_E_IO;
     const size_t slash = path.find_last_of('/');
     const std::string dir = slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : path.substr(0, slash));
-    const int fd = open(dir.c_str(), O_RDONLY | O_DIRECTORY);
-    if (fd < 0) return RL_E_IO;
-    const bool ok = fsync(fd) == 0;
+    // (the rename HAS happened; the directory's fsync is best effort where a file system does not offer it -- some NFS,
+    // CIFS and FUSE mounts answer EINVAL / ENOTSUP, a read-only bind EROFS -- and only a real I/O error fails the save)
+    auto soft = [](int e) { return e == EINVAL || e == ENOTSUP || e == EROFS || e == EACCES || e == EBADF; };
+    int fd;
+    do fd = open(dir.c_str(), O_RDONLY | O_DIRECTORY); while (fd < 0 && errno == EINTR);
+    if (fd < 0) return soft(errno) ? RL_OK : RL_E_IO;
+    int rc;
+    do rc = fsync(fd); while (rc != 0 && errno == EINTR);
+    const int e = errno;
     close(fd);
-    return ok ? RL_OK : RL_E_IO;
+    return (rc == 0 || soft(e)) ? RL_OK : RL_E_IO;
 }
 
 std::vector<ResumeEntry> read_sidecar(const char* checkpoint, uint32_t photons, const RlAppConfig* config, size_t ranks) {

@@ -669,7 +669,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         } else if (n_members == 14u) {
             if (split) RL_MEMBERS(7u) else RL_MEMBERS(14u)
         } else RL_MEMBERS(n_members)
-#else // RL_CLUSTER_K_CHOICES: one compare decides (the three-way form was a tree of six scalar instructions per round)
+#else // RL_CLUSTER_K_CHOICES = {10, 14}: one compare decides (the three-way form was a tree of six scalar instructions per round; rl_scene_create refuses any other size)
         if (n_members == 10u) {
             if (split) RL_MEMBERS(5u) else RL_MEMBERS(10u)
         } else {
@@ -974,7 +974,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 template <int STAGE, bool FUSED, bool OPEN, bool CYL>
 __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, const RlSceneLayout& lay, const RlTraceJob& job, RlMappedPhoton* __restrict__ photons,
                                               float* __restrict__ plot, unsigned long long* __restrict__ queue, const RlJobEntry* jobs, RlOpenDev* od, RlOpenCtl* ctl) {
-    extern __shared__ __attribute__((aligned(16))) RlF4 smem[];
+    extern __shared__ __attribute__((aligned(512))) RlF4 smem[]; // (512: the ring pushes OR slot offsets into a wave's scratch address, RL_RING_SLOT)
     const RlF4* base = scene; // the tables
     const RlF4* big = scene;  // the per-sphere and per-object arrays
     RlWaveScratch* scratch = (RlWaveScratch*)smem;
@@ -1014,6 +1014,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     sv.records = big; // (a tables-only stage completes its hits from the blob in global memory, like its spheres)
     const uint32_t lane = threadIdx.x & 63u;
     RlWaveScratch* ws = &scratch[threadIdx.x >> 6];
+#if defined(RL_STATS) || defined(RL_DEBUG_ALIGN)
+    // (the ring addressing is only right on a 512-byte aligned scratch, i.e. with the dynamic LDS at offset 0 of the
+    // workgroup's allocation and nothing static in front of it; the diagnostic builds stop here if that ever changes)
+    if (((uint32_t)(size_t)(RlLdsU32*)ws & 511u) != 0u) __builtin_trap();
+#endif
     typedef __attribute__((address_space(3))) float RlLdsF32;
     RlLdsF32* stash = (RlLdsF32*)&ws->stash[0][0];
 
@@ -1848,6 +1853,38 @@ __global__ void rl_math_probe_kernel(int fn, const float* __restrict__ x, float*
     case 15: r = rl_acosf_d(v); break;
     }
     y[i] = r;
+}
+
+// Diagnostics (robigo_luculenta_debug.h): the short forms of rl_math.h / rl_core.h against the compiler's correctly rounded
+// expansions for EVERY float whose bits lie in [lo, hi) (and, both_signs, its negative): what tools/sqrt_exhaustive.hip did with
+// its own copies of the formulas, here with the functions the kernels call -- 1.9 G / 6.7 G arguments in seconds, no host traffic.
+// fn: 16 rl_sqrtf vs sqrtf, 17 rl_recipf vs 1 / x, 18 rl_div200f vs x / 200.  Consecutive floats share a wave, so a wave takes the
+// short form exactly where the range test of the function lets it.  bad[0] = mismatches, bad[1] = arguments compared.
+__global__ __launch_bounds__(RL_BLOCK) void rl_math_sweep_kernel(int fn, uint32_t lo, uint32_t hi, int both_signs, unsigned long long* __restrict__ bad,
+                                                                 uint32_t* __restrict__ example) {
+    const uint64_t stride = (uint64_t)gridDim.x * RL_BLOCK;
+    unsigned long long mine = 0, seen = 0;
+    uint32_t last = 0;
+    // (whole waves iterate together: the short forms decide per wave)
+    const uint64_t n = (uint64_t)hi - lo, rounds = (n + stride - 1) / stride;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t off = r * stride + (uint64_t)blockIdx.x * RL_BLOCK + threadIdx.x;
+        const bool live = off < n;
+        const uint32_t bits = lo + (uint32_t)(live ? off : 0);
+        for (int sign = 0; sign <= (both_signs ? 1 : 0); ++sign) {
+            const float x = rl_u2f(bits | ((uint32_t)sign << 31));
+            float got, want;
+            if (fn == 16) got = rl_sqrtf(x), want = sqrtf(x);
+            else if (fn == 17) got = rl_recipf(x), want = 1.0f / x;
+            else got = rl_div200f(x), want = x / 200.0f;
+            if (live) {
+                seen += 1;
+                if (rl_f2u(got) != rl_f2u(want) && !(got != got && want != want)) mine += 1, last = rl_f2u(x);
+            }
+        }
+    }
+    if (mine) atomicAdd(&bad[0], mine), example[0] = last;
+    atomicAdd(&bad[1], seen);
 }
 
 // Diagnostics (robigo_luculenta_debug.h): the prism shortcut and the Compound tree for n rays against one prism of the scene.

@@ -130,6 +130,8 @@ RL_HD float rl_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 RL_HD uint32_t rl_object_bits(uint32_t surface_kind, uint32_t material_kind, uint32_t group_index) {
     return (surface_kind & 7u) | ((material_kind & 7u) << 3) | (group_index << 6);
 }
+static_assert(RL_SURFACE_HEX_PRISM <= 7 && RL_MATERIAL_SOAP_BUBBLE <= 7, "rl_object_bits keeps three bits for the surface kind and three for the material kind");
+static_assert(RL_GROUP_GP == 3 || RL_GROUP_GP == 4, "rl_scan_wave's unrolled ring-S round tests a group's first three children unconditionally and a fourth if there is one");
 RL_HD uint32_t rl_object_surface(uint32_t bits) { return bits & 7u; }
 RL_HD uint32_t rl_object_material(uint32_t bits) { return (bits >> 3) & 7u; }
 RL_HD uint32_t rl_object_group(uint32_t bits) { return bits >> 6; }

@@ -253,7 +253,14 @@ def test_bench_line_counts_its_own_counters_when_rocprofv3_is_on_the_box():
     assert live["seconds"] < 100
     # the occupancy the design leans on, from the counters: a resident trace kernel holds 4 waves per SIMD (the
     # compiler reports 118-120 VGPRs, rocprofv3 "VGPR_Count 60" -- the unified register file counted in halves)
-    assert 3.5 < live["resident_waves_per_simd"] <= 4.02
+    assert 3.5 < live["resident_waves_per_simd"] <= 5.02
+    # the driver-parsed roofline.frac IS the utilisation counted in this run (<= 1), achieved / peak say the same in
+    # lane-operations per second, and the reference-flops figure (> 1: the kernel culls the reference's scan) is labelled a speed-up
+    rf = line["roofline"]
+    assert rf["frac"] == live["useful_lane_slots_vs_2cyc"] and 0.3 < rf["frac"] <= 1.0 and rf["frac_source"].startswith("executed_live")
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9 and rf["unit"] == "Tlane-op/s"
+    assert rf["algorithmic"]["frac"] == rf["frac_algorithmic"] and "SPEED-UP" in rf["algorithmic"]["is"]
+    assert 0.5 < rf["issue_ceiling"]["kernel_vs_plain_stream"] < 1.3
 
 
 def test_bench_with_more_ranks_than_gpus_falls_back_instead_of_hanging(R):

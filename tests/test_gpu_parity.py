@@ -98,16 +98,25 @@ def test_sf10_index_decided_from_the_cheap_evaluation_is_the_reference_f64_expre
 
 
 def _exhaustive_slices(lo, hi, step):
-    """The slices of [lo, hi) an exhaustive sweep visits.  RL_EXHAUSTIVE=1: all of them (1.9 G / 3.4 G floats through the probe and
-    numpy: minutes and many GB of host traffic -- what tools/sqrt_exhaustive.hip does on the device in seconds, and what
-    profiles/r04_sqrt_exhaustive.txt records).  By default: every eighth slice, rotating with the day so that the
-    suite's runs cover all of them between them, plus the first and the last."""
+    """The slices of [lo, hi) that go through the HOST comparison (the library's probe against numpy).  The exhaustive part of these
+    tests runs on the device (R.math_sweep: every argument, every run, seconds); the host comparison pins what the device compares
+    against -- the compiler's IEEE expansion -- on a FIXED sample: every eighth slice from phase RL_SLICE_PHASE (default 0) plus the
+    first and the last, so the same commit tests the same inputs on every day (rounds 4-5 rotated the phase with the
+    date).  RL_EXHAUSTIVE=1: all slices through the host as well (minutes, many GB of host traffic)."""
     firsts = list(range(lo, hi, step))
     if os.environ.get("RL_EXHAUSTIVE"):
         return firsts
-    import datetime
-    phase = datetime.date.today().toordinal() % 8
+    phase = int(os.environ.get("RL_SLICE_PHASE", "0")) % 8
     return sorted(set(firsts[phase::8]) | {firsts[0], firsts[-1]})
+
+
+def _device_sweep(fn, lo, hi, both_signs):
+    """Every float with bits in [lo, hi) (and its negative): the library's short form against the compiler's correctly rounded
+    expansion, on the device.  Returns the number of arguments compared."""
+    bad, seen, example = R.math_sweep(fn, lo, hi, both_signs)
+    assert bad == 0, "%s: %d of %d arguments differ from the IEEE result, e.g. bits 0x%08x" % (fn, bad, seen, example)
+    assert seen == (hi - lo) * (2 if both_signs else 1)
+    return seen
 
 
 def test_short_square_root_is_the_ieee_one_for_every_normal_float():
@@ -118,10 +127,12 @@ def test_short_square_root_is_the_ieee_one_for_every_normal_float():
     NaN, negatives) must take the compiler's form and give the IEEE result too."""
     lo, hi = 0x0f800000, 0x7f800000
     step = 1 << 25
-    for first in _exhaustive_slices(lo, hi, step):
+    assert _device_sweep("sqrt_short", lo, hi, False) == 1_879_048_192   # all of them, on the device, against the compiler's sqrtf
+    assert _device_sweep("sqrt_short", 0x00800000, lo, False) > 0        # the tiny normals below the short form's range: its fallback
+    for first in _exhaustive_slices(lo, hi, step):                        # ... and a fixed sample against numpy, through the host
         x = np.arange(first, min(first + step, hi), dtype=np.uint32).view(np.float32)
         got = R.math_probe("sqrt_short", x)
-        assert got.view(np.uint32).tobytes() == np.sqrt(x).view(np.uint32).tobytes(), hex(first)
+        assert got.view(np.uint32).tobytes() == np.sqrt(x).view(np.uint32).tobytes(), "slice 0x%08x (RL_SLICE_PHASE=%s)" % (first, os.environ.get("RL_SLICE_PHASE", "0"))
     rng = np.random.default_rng(5)
     odd = rng.integers(0, 1 << 32, 1 << 20, dtype=np.uint64).astype(np.uint32).view(np.float32)   # every class of float, mixed within waves
     odd[::3] = np.array([0.0, -0.0, np.inf, 1e-40, 3e-30, 1.0], np.float32)[rng.integers(0, 6, len(odd[::3]))]
@@ -141,9 +152,11 @@ def test_short_one_operand_divisions_are_the_ieee_ones(fn):
     ref = (lambda x: np.float32(1.0) / x) if fn == "recip_short" else (lambda x: x / np.float32(200.0))
     lo, hi = 0x0d800000, 0x71800000
     step = 1 << 25
-    for first in _exhaustive_slices(lo, hi, step):
+    assert _device_sweep(fn, lo, hi, True) == 3_355_443_200               # every such float of either sign, on the device
+    assert _device_sweep(fn, 0x00800000, lo, True) > 0 and _device_sweep(fn, hi, 0x7f800000, True) > 0   # outside the range: the fallback
+    for first in _exhaustive_slices(lo, hi, step):                        # ... and a fixed sample against numpy, through the host
         x = np.arange(first, min(first + step, hi), dtype=np.uint32).view(np.float32)
-        assert R.math_probe(fn, x).view(np.uint32).tobytes() == ref(x).view(np.uint32).tobytes(), hex(first)
+        assert R.math_probe(fn, x).view(np.uint32).tobytes() == ref(x).view(np.uint32).tobytes(), "slice 0x%08x (RL_SLICE_PHASE=%s)" % (first, os.environ.get("RL_SLICE_PHASE", "0"))
     rng = np.random.default_rng(6)
     neg = (rng.integers(lo, hi, 1 << 22, dtype=np.uint64).astype(np.uint32) | np.uint32(0x80000000)).view(np.float32)
     assert R.math_probe(fn, neg).view(np.uint32).tobytes() == ref(neg).view(np.uint32).tobytes()

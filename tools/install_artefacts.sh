@@ -28,7 +28,7 @@ tag = sys.argv[1]
 d = json.load(open("profiles/%s_bench.json" % tag))
 e = d["roofline"]["executed"]
 print("frac_executed", d["roofline"].get("frac_executed"), "valu_busy", d["roofline"].get("valu_busy"))
-print("Mrays/s %.1f  Mpaths/s %.1f  batches/s %.0f  ms/step %.2f  algorithmic frac %.3f  cpu %.2f Mrays/s (%d cores)"
+print("Mrays/s %.1f  Mpaths/s %.1f  batches/s %.0f  ms/step %.2f  frac (executed lane-slots) %.3f  cpu %.2f Mrays/s (%d cores)"
       % (d["value"], d["mpaths_per_s"], d["batches_per_s"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"]))
 print("executed:", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()})
 print("others:", [(o["config"], round(o["value"]), (o.get("executed") or {}).get("active_lanes")) for o in d["config"]["others"]])
