@@ -340,6 +340,62 @@ RL_HD RlCand rl_compound_pick(RlCand a, RlCand b) {
 // HexagonalPrism = Compound<InfinitePrism[0,1,2], Compound<InfinitePrism[3,4,5], ThickPlane[6,7]>>
 // with InfinitePrism[a,b,c] = Compound<Compound<a,b>,c> (geometry.rs:409-416).  pr points at the
 // prism's 16 half-space records.
+#if defined(__HIP_DEVICE_COMPILE__)
+// The device's form of the tree below: the same operations on the same values, but nothing of a half-space is kept in registers
+// between its uses -- every plane test and every inside test loads its normal and offset again (through an index the optimiser
+// cannot see through, or it would merge the loads and keep all 48 values live as the literal form does: the tree then sets the
+// register count of the whole trace kernel, 56 registers for something 3.6 % of the prism rounds reach).  Twice the loads, a fifth
+// of the registers; what a round that evaluates the tree costs is immaterial next to what a register costs every wave of the
+// kernel (occupancy).
+__device__ __forceinline__ RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
+    const float NONE = __builtin_inff();
+    float t[8];
+    auto plane = [&](int k, RlF3* n, RlF3* off) {
+        uint32_t kk = 2u * (uint32_t)k;
+        asm volatile("" : "+v"(kk));
+        *n = rl_xyz(pr[kk]);
+        *off = rl_xyz(pr[kk + 1u]);
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        RlF3 n, off;
+        plane(k, &n, &off);
+        float dn;
+        const float tk = rl_plane_t(n, off, o, dir, &dn);
+        t[k] = tk > 0.0f ? tk : NONE;
+    }
+    auto filt = [&](RlCand c, uint32_t mask) -> RlCand {
+        const RlF3 pos = rl_add(o, rl_mul(dir, c.t));
+        bool in = true;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (mask & (1u << j)) {
+                RlF3 n, off;
+                plane(j, &n, &off);
+                in = in & rl_inside(n, off, pos);
+            }
+        if (!in) c.t = NONE;
+        return c;
+    };
+    auto leaf = [&](int k) -> RlCand {
+        RlCand c;
+        c.t = t[k];
+        c.k = (uint32_t)k;
+        return c;
+    };
+    auto inf_prism = [&](int a, int b, int c) -> RlCand {
+        const RlCand ab = rl_compound_pick(filt(leaf(a), 1u << b), filt(leaf(b), 1u << a));
+        return rl_compound_pick(filt(ab, 1u << c), filt(leaf(c), (1u << a) | (1u << b)));
+    };
+    const RlCand ip_bevel = inf_prism(0, 1, 2);
+    const RlCand ip_main = inf_prism(3, 4, 5);
+    const RlCand thick = rl_compound_pick(filt(leaf(6), 1u << 7), filt(leaf(7), 1u << 6));
+    const RlCand prism = rl_compound_pick(filt(ip_main, 0xC0u), filt(thick, 0x38u));
+    RlCand hit = rl_compound_pick(filt(ip_bevel, 0xF8u), filt(prism, 0x07u));
+    if (!(hit.t < NONE)) hit.t = -1.0f;
+    return hit;
+}
+#else
 RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     const float NONE = __builtin_inff();
     RlF3 n[8], off[8];
@@ -387,6 +443,7 @@ RL_HD RlCand rl_hex_prism(const RlF4* pr, RlF3 o, RlF3 dir) {
     if (!(hit.t < NONE)) hit.t = -1.0f;
     return hit;
 }
+#endif
 
 // ---- the same result without walking the tree ----------------------------------------------------------------------
 // rl_hex_prism above costs ~600 instructions: 8 plane tests with an IEEE division each and 25 inside tests.  The prism

@@ -43,6 +43,15 @@
 #ifndef RL_TRACE_BLOCK
 #define RL_TRACE_BLOCK 1024 // trace kernel: one workgroup of 16 waves per CU shares one LDS copy of the scene
 #endif
+#ifndef RL_TRACE_WPS
+#define RL_TRACE_WPS 4      // waves per SIMD the trace kernel is compiled for (launch bounds; the register caps below follow from it)
+#endif
+#ifndef RL_TRACE_VGPRS
+#define RL_TRACE_VGPRS (RL_TRACE_WPS == 4 ? 128 : 96)      // plain launches: all a wave can have at that occupancy (512 / waves, in eights)
+#endif
+#ifndef RL_TRACE_VGPRS_OPEN
+#define RL_TRACE_VGPRS_OPEN (RL_TRACE_WPS == 4 ? 120 : 96) // open launches leave the small kernels of the other units their registers
+#endif
 #ifndef RL_W_S
 #define RL_W_S 1 // ring-S rounds of the plain launches: the children's bounds requested ahead of the cross-lane fetch (A/B builds set 0)
 #endif
@@ -54,6 +63,16 @@
 #endif
 #ifndef RL_W_PR
 #define RL_W_PR 1 // prism rounds: the first plane's two records likewise
+#endif
+#ifndef RL_MEMBER_FENCE
+#define RL_MEMBER_FENCE (RL_TRACE_WPS > 4)
+#endif
+// Five waves per SIMD leave a wave 96 registers: the options that buy latency with registers are off there unless a build asks
+#ifndef RL_LEAN_SPLIT
+#define RL_LEAN_SPLIT (RL_TRACE_WPS <= 4)
+#endif
+#ifndef RL_LEAN_HOIST
+#define RL_LEAN_HOIST (RL_TRACE_WPS <= 4)
 #endif
 #define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills) in large launches
 
@@ -657,6 +676,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             uint32_t failed = 0; /* one bit per member: the sign of the test's margin, shifted in with one v_alignbit */  \
             for (uint32_t j = 0; j < (N); ++j) {                                                                         \
                 const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
+                if (RL_MEMBER_FENCE) asm volatile("" ::: "memory"); /* ONE record in flight: without it a tight register budget makes the scheduler request all N up front and spill them */ \
                 failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
             }                                                                                                            \
@@ -1481,7 +1501,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
         // (... and their children's bounds requested ahead of the fetch wherever that leaves the instantiation spill-free: not in the
         // open launches of a tables-only scene, 64-bit global addresses again)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) && RL_W_S, STAGE == RL_STAGE_ALL>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        const RlHit hit = rl_scan_wave<CYL, !OPEN && RL_LEAN_SPLIT, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) && RL_W_S && RL_LEAN_HOIST, STAGE == RL_STAGE_ALL>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
@@ -1613,14 +1633,14 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
 //     BESIDE a resident trace kernel instead of behind it.
 // (amdgpu_num_vgpr counts in units of two registers on this target.)
 template <int STAGE, bool FUSED, bool CYL>
-__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(64))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
+__global__ __launch_bounds__(RL_TRACE_BLOCK, RL_TRACE_WPS) __attribute__((amdgpu_num_vgpr(RL_TRACE_VGPRS / 2))) void rl_trace_kernel(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
                                                                                                        RlMappedPhoton* __restrict__ photons, float* __restrict__ plot,
                                                                                                        unsigned long long* __restrict__ queue, const RlJobEntry* jobs,
                                                                                                        RlOpenDev* od, RlOpenCtl* ctl) {
     rl_trace_body<STAGE, FUSED, false, CYL>(scene, lay, job, photons, plot, queue, jobs, od, ctl);
 }
 template <int STAGE, bool FUSED, bool CYL>
-__global__ __launch_bounds__(RL_TRACE_BLOCK, 4) __attribute__((amdgpu_num_vgpr(60))) void rl_trace_kernel_open(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
+__global__ __launch_bounds__(RL_TRACE_BLOCK, RL_TRACE_WPS) __attribute__((amdgpu_num_vgpr(RL_TRACE_VGPRS_OPEN / 2))) void rl_trace_kernel_open(const RlF4* __restrict__ scene, RlSceneLayout lay, RlTraceJob job,
                                                                                                             RlMappedPhoton* __restrict__ photons, float* __restrict__ plot,
                                                                                                             unsigned long long* __restrict__ queue, const RlJobEntry* jobs,
                                                                                                             RlOpenDev* od, RlOpenCtl* ctl) {
