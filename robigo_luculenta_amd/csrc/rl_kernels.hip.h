@@ -64,6 +64,9 @@
 #ifndef RL_W_PR
 #define RL_W_PR 1 // prism rounds: the first plane's two records likewise
 #endif
+#ifndef RL_EMIT_GLOBAL
+#define RL_EMIT_GLOBAL 0 // 1: the emitter queue of plain fused launches lives in global memory (five waves per SIMD: LDS per wave is what is short)
+#endif
 #ifndef RL_MEMBER_FENCE
 #define RL_MEMBER_FENCE (RL_TRACE_WPS > 4)
 #endif
@@ -344,9 +347,19 @@ struct RlWaveScratch {
     float stash[10][64];
     // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
     // until (about) 64 of them can be evaluated and splatted with a full exec mask.
+#if !RL_EMIT_GLOBAL
     float emit[5][64];
+#else
+    // (RL_EMIT_GLOBAL: the plain fused launches keep this queue in global memory -- RL_EMIT_QUEUE_FLOATS below -- and the wave's scratch is
+    // 1,280 bytes smaller, padded to the next multiple of 512)
+    float pad_[64]; // 6,912 -> 7,168 bytes
+#endif
 };
-static_assert(sizeof(RlWaveScratch) == 8192, "rl_scan_wave's ring addressing wants the wave's scratch 512-byte aligned");
+static_assert(sizeof(RlWaveScratch) % 512 == 0, "rl_scan_wave's ring addressing wants the wave's scratch 512-byte aligned");
+// RL_EMIT_GLOBAL: one emitter queue per wave of the grid, in device memory: 5 rows of 64 floats (the layout of RlWaveScratch::emit).
+// A path ends on a light ~2 times per wave iteration: five fire-and-forget global stores instead of five LDS writes, read back once
+// per ~30 iterations when a batch runs (behind an s_waitcnt vmcnt(0), with loads that bypass the L1).
+#define RL_EMIT_QUEUE_FLOATS 320u
 
 typedef float RlV4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) RlV4 RlLdsV4;
@@ -1078,7 +1091,22 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     RlLdsU32* wg_seg = (RlLdsU32*)&wgp->seg[0];
     RlLdsU32* wg_flushed_at = (RlLdsU32*)&wgp->flushed_at;
     RlLdsU32* wg_poll = (RlLdsU32*)&wgp->poll[0];
+    constexpr bool EMITG = RL_EMIT_GLOBAL != 0; // (a build option: every fused launch of such a build, plain or open, gets its queues through `photons`)
+#if !RL_EMIT_GLOBAL
     RlLdsF32* emit = (RlLdsF32*)&ws->emit[0][0];
+    float* emit_g = nullptr;
+#else
+    RlLdsF32* emit = nullptr;
+    float* emit_g = (float*)photons + (size_t)(blockIdx.x * (RL_TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) * RL_EMIT_QUEUE_FLOATS; // (fused: `photons` carries the queues)
+#endif
+    auto emit_put = [&](uint32_t row, uint32_t slot, float v) {
+        if (EMITG) emit_g[row * 64u + slot] = v;
+        else emit[row * 64u + slot] = v;
+    };
+    auto emit_get = [&](uint32_t row, uint32_t slot) -> float {
+        if (EMITG) return rl_u2f(__hip_atomic_load((const uint32_t*)emit_g + row * 64u + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        return emit[row * 64u + slot];
+    };
     if (OPEN) {
         for (uint32_t i = threadIdx.x; i < sizeof(RlOpenWg) / 4; i += RL_TRACE_BLOCK) ((RlLdsU32*)wgp)[i] = 0;
         __syncthreads();
@@ -1148,16 +1176,17 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         RL_STAT(RL_ST_EMIT_LANES, count);
         if (OPEN && emit_pend != 0) settle(); // (a second batch in one iteration -- 64 paths ending at once: count the first before its tags go)
         rl_wave_sync();
+        if (EMITG) asm volatile("s_waitcnt vmcnt(0) ; the queue's stores have reached the L2" ::: "memory");
         if (lane < count) {
             const uint32_t slot = (e_head + lane) & 63u;
-            const float sx = emit[0 * 64 + slot], sy = emit[1 * 64 + slot], wavelength = emit[2 * 64 + slot];
-            const uint32_t tagged = rl_f2u(emit[4 * 64 + slot]);
+            const float sx = emit_get(0, slot), sy = emit_get(1, slot), wavelength = emit_get(2, slot);
+            const uint32_t tagged = rl_f2u(emit_get(4, slot));
             // (OPEN: settle() counts these paths per call an iteration from now, when the queue's slots may hold newer entries:
             // the tags wait in ring B, which is empty between two scans)
             if (OPEN) ((RlLdsU32*)ws->ring_b)[lane] = tagged;
             float* target = plot;
             if (OPEN) target = (float*)jobs[tagged >> 24].target;
-            const float value = rl_emission(sv, emit[3 * 64 + slot], wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
+            const float value = rl_emission(sv, emit_get(3, slot), wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
             if (value != 0.0f) { // adding +0 is the identity
                 const RlF3 cie = rl_mul(rl_tristimulus(sv.cie, wavelength), value);
                 uint32_t width = job.width, height = job.height; // opaque: `width - 1` etc. are re-derived here instead of living in
@@ -1587,11 +1616,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 }
                 if (ended_on_emitter) {
                     const uint32_t slot = rl_mbcnt_from(m, e_tail) & 63u;
-                    emit[0 * 64 + slot] = p.sx;
-                    emit[1 * 64 + slot] = p.sy;
-                    emit[2 * 64 + slot] = p.wavelength;
-                    emit[3 * 64 + slot] = p.intensity;
-                    emit[4 * 64 + slot] = rl_u2f(emit_obj);
+                    emit_put(0, slot, p.sx);
+                    emit_put(1, slot, p.sy);
+                    emit_put(2, slot, p.wavelength);
+                    emit_put(3, slot, p.intensity);
+                    emit_put(4, slot, rl_u2f(emit_obj));
                     ended_on_emitter = false;
                 }
                 e_tail += n_new;
