@@ -64,6 +64,9 @@
 #ifndef RL_W_PR
 #define RL_W_PR 1 // prism rounds: the first plane's two records likewise
 #endif
+#ifndef RL_SMALL_UNROLL
+#define RL_SMALL_UNROLL 1
+#endif
 #ifndef RL_EMIT_GLOBAL
 #define RL_EMIT_GLOBAL 0 // 1: the emitter queue of plain fused launches lives in global memory (five waves per SIMD: LDS per wave is what is short)
 #endif
@@ -513,8 +516,8 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // order.  Both record lists are in object order (rl_scene.cpp), so a plain `t < best.t` decides within each; it also decides
     // between them when every paraboloid's object precedes every plane's (RlSceneLayout::small_ordered, the built-in scenes) --
     // two compares, two mask operations and a branch less per candidate than the general form, which other scenes take.
-#define RL_SMALL_PRIMITIVES(NEARER)                                                                   \
-    for (uint32_t i = 0; i < n_parabs; ++i) {                                                         \
+#define RL_SMALL_PRIMITIVES(NEARER, NP, NL)                                                           \
+    _Pragma("unroll") for (uint32_t i = 0; i < (NP); ++i) {                                           \
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];       \
         if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* records in LDS: 16-byte loads (rl_hex_prism_fast), a 12-byte LDS read takes twice the LDS time */ \
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);                  \
@@ -524,7 +527,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             best.obj = obj;                                                                           \
         }                                                                                             \
     }                                                                                                 \
-    for (uint32_t i = 0; i < n_planes; ++i) {                                                         \
+    _Pragma("unroll") for (uint32_t i = 0; i < (NL); ++i) {                                           \
         const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];                                  \
         float dn;                                                                                     \
         const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);                              \
@@ -540,10 +543,56 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         }                                                                                             \
     }
 #define RL_NEARER_ORDERED(T, OBJ, BEST) ((T) < (BEST).t)
-    if (small_ordered != 0u) {
-        RL_SMALL_PRIMITIVES(RL_NEARER_ORDERED)
+    // (three paraboloids and three planes / circles -- the room of every built-in scene, app.rs:166-236 -- get straight-line code: the
+    // records' addresses are immediates, their loads can be requested ahead of the arithmetic that is in the way, and the two loops'
+    // counters and branches go; any other count takes the loops)
+    if (RL_SMALL_UNROLL && small_ordered != 0u && n_parabs == 3u && n_planes == 3u) {
+        // One object's records in flight behind the previous object's arithmetic: six exposed LDS round trips become one.  (The
+        // arithmetic has wave-uniform fallback branches -- short square root, one-division form -- so the scheduler, which works on
+        // basic blocks, never moves a load up by itself; the fences keep the loads where they are written.)
+        auto parab = [&](const RlF4& r0, const RlF4& r1, const RlF4& r2) {
+            if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* 16-byte LDS loads */
+            const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
+            const bool nearer = !(t < 0.0f) & (t < best.t);
+            best.t = nearer ? t : best.t;
+            best.obj = nearer ? rl_f2u(r0.w) : best.obj;
+        };
+        auto plane = [&](const RlF4& r0, const RlF4& r1) {
+            float dn;
+            const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
+            bool hit = t > 0.0f;
+            if (hit && r0.w >= 0.0f) {
+                const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
+                hit = rl_dot(dp, dp) <= r0.w;
+            }
+            const bool nearer = hit & (t < best.t);
+            best.t = nearer ? t : best.t;
+            best.obj = nearer ? rl_f2u(r1.w) : best.obj;
+        };
+#define RL_FENCE asm volatile("" ::: "memory")
+        const RlF4 a0 = sv.parabs[0], a1 = sv.parabs[1], a2 = sv.parabs[2];
+        RL_FENCE;
+        const RlF4 b0 = sv.parabs[3], b1 = sv.parabs[4], b2 = sv.parabs[5];
+        RL_FENCE;
+        parab(a0, a1, a2);
+        const RlF4 c0 = sv.parabs[6], c1 = sv.parabs[7], c2 = sv.parabs[8];
+        RL_FENCE;
+        parab(b0, b1, b2);
+        const RlF4 d0 = sv.planes[0], d1 = sv.planes[1];
+        RL_FENCE;
+        parab(c0, c1, c2);
+        const RlF4 e0 = sv.planes[2], e1 = sv.planes[3];
+        RL_FENCE;
+        plane(d0, d1);
+        const RlF4 f0 = sv.planes[4], f1 = sv.planes[5];
+        RL_FENCE;
+        plane(e0, e1);
+        plane(f0, f1);
+#undef RL_FENCE
+    } else if (small_ordered != 0u) {
+        RL_SMALL_PRIMITIVES(RL_NEARER_ORDERED, n_parabs, n_planes)
     } else {
-        RL_SMALL_PRIMITIVES(rl_nearer)
+        RL_SMALL_PRIMITIVES(rl_nearer, n_parabs, n_planes)
     }
 #undef RL_NEARER_ORDERED
 #undef RL_SMALL_PRIMITIVES

@@ -6,6 +6,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -950,6 +951,12 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
 #endif
                 ClusterPlan candidate = plan_clusters(sph_in, clusters, k, g);
                 candidate.cost = plan_cost(candidate, rays);
+                // (RL_PLAN="k,g": measurement runs force one plan -- tools/plan_ab.sh -- to check the cost model against the kernel as it is now)
+                if (const char* forced = std::getenv("RL_PLAN")) {
+                    unsigned fk = 0, fg = 0;
+                    if (std::sscanf(forced, "%u,%u", &fk, &fg) == 2 && fk == k && fg == g) candidate.cost = -1.0;
+                }
+                if (std::getenv("RL_PLAN_VERBOSE")) std::fprintf(stderr, "rl: plan k=%u g=%u: %zu clusters, estimated cost %.4f\n", k, g, candidate.clusters.size(), candidate.cost);
                 if (first || candidate.cost < plan.cost * 0.995) plan = candidate; // (a later, larger plan has to win by more than the estimate's noise)
                 first = false;
             }
