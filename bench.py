@@ -470,6 +470,17 @@ def rccl_report(world, rccl_used, info, sum_worlds, backend):
             "library": info.get("library"), "backend_used": "rccl" if rccl_used else backend}
 
 
+def metric_name(W, H, world, scaling):
+    """BASELINE.json's metric; at N > 1 the name also says which scaling mode `value` is (SURVEY 8(e) defines the
+    metric on a fixed total -- strong --, the driver's contract lets per-GPU work stay fixed -- weak, the default; every N > 1 line
+    carries BOTH in `scaling_detail`, and `value` is the one named here)."""
+    name = "Mrays/sec on built-in scene at %dx%d" % (W, H)
+    if world > 1:
+        name += ("; %d GPUs, WEAK scaling (per-GPU paths fixed; strong in scaling_detail)" if scaling == "weak"
+                 else "; %d GPUs, STRONG scaling (total paths fixed; weak in scaling_detail)") % world
+    return name
+
+
 def scaling_detail(world, scaling, value, n1, other):
     """`scaling_detail` of an N > 1 line: the one-GPU rate of the same run and both scaling modes against it.
     efficiency = N-rank rays/s / (N x the one-GPU rays/s); SURVEY 8(e)'s target is >= 0.9 at N = 8."""
@@ -497,7 +508,7 @@ def dry_run(args, D, R, rank, world, paths_per_launch, scaling):
              "ms_per_step": o_dt / args.steps * 1e3, "paths_per_step_per_gpu": paths / args.steps / world, "what": "dry run"}
     if rank == 0:
         print(json.dumps({
-            "metric": "Mrays/sec on built-in scene at 1920x1080", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "metric": metric_name(1920, 1080, world, scaling), "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "none (dry run of the control plane: no GPU work, made-up counters)",
             "config": {"workload": "dry run", "paths_per_launch": paths_per_launch, "total_paths_per_step": paths_per_launch * args.launches_per_step * world,
@@ -721,7 +732,7 @@ def main():
         ex = executed_from_profile(R, args.config, args.fetch, rays_per_launch, launch_ms, paths_per_launch)
         executed, traffic = ex if isinstance(ex, tuple) else (ex, None)
         out = {
-            "metric": "Mrays/sec on built-in scene at %dx%d" % (W, H),
+            "metric": metric_name(W, H, world, scaling),
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -29,7 +29,7 @@ pub const RL_COMM_ID_BYTES: usize = 128;
     pub width: u32, pub height: u32, pub device: c_int, pub concurrency: u32, pub photons_per_batch: u32,
     pub seed: u64, pub stream: u32, pub builtin_scene: c_int, pub builtin_param: c_int, pub max_batches: u64,
     pub tonemap_interval_ms: i64, pub fused: c_int, pub output_ppm: *const c_char, pub checkpoint: *const c_char,
-    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32, pub first_batch: u64, pub n_devices: u32, pub blocking_trace: c_int, pub devices: *const c_int,
+    pub resume: c_int, pub verbose: c_int, pub sleep_us: u32, pub first_batch: u64, pub n_devices: u32, pub blocking_trace: c_int, pub devices: *const c_int, pub threads: u32,
 }
 #[repr(C)] #[derive(Copy, Clone, Default)] pub struct RlAppStats {
     pub batches: u64, pub paths: u64, pub segments: u64, pub tasks: [u64; 5], pub seconds: c_double, pub kernel_ms: c_double,

@@ -341,7 +341,7 @@ int rl_scheduler_performance(RlScheduler* s, float* mean, float* stddev);
 typedef struct RlAppConfig {
     uint32_t width, height;      /* main.rs:47-48 (1280 x 720 there) */
     int device;                  /* GPU that takes the place of the CPU worker pool */
-    uint32_t concurrency;        /* worker threads; the reference uses num_cpus::get() (app.rs:55) */
+    uint32_t concurrency;        /* scheduler depth = worker threads unless `threads` says otherwise; the reference uses num_cpus::get() (app.rs:55) */
     uint32_t photons_per_batch;  /* 0 -> 1024*512 (trace_unit.rs:67) */
     uint64_t seed;
     uint32_t stream;             /* RNG stream (multi-GPU: the rank) */
@@ -376,6 +376,11 @@ typedef struct RlAppConfig {
                                     device only ever has `concurrency` batches to work on) */
     const int* devices;          /* n_devices device indices, rank 0 first (gather, tonemap and output live there);
                                     NULL = device, device + 1, ...  A device may be listed more than once. */
+    uint32_t threads;            /* host worker threads; 0 = `concurrency`, as in the reference (app.rs:55,66: one thread per unit
+                                    of scheduler depth).  The scheduler's pools are sized by `concurrency` (3 x trace units,
+                                    concurrency / 2 plot units, task_scheduler.rs:95-96) -- how many batches the DEVICE can have in
+                                    flight; a task here only begins or enqueues device work, so a host with few cores per GPU
+                                    sets e.g. concurrency = 16, threads = 2: the pool stays deep, two threads issue it */
 } RlAppConfig;
 
 typedef struct RlAppStats {

@@ -20,6 +20,13 @@ int rl_debug_math_probe(int device, int fn, const float* x, float* y, uint32_t n
  * its negative when both_signs != 0.  counts[0] = arguments whose results differ, counts[1] = arguments compared, *example = the
  * bits of one argument that differs.  Seconds for the whole normal range: the exhaustive checks of the -m gpu suite. */
 int rl_debug_math_sweep(int device, int fn, uint32_t lo_bits, uint32_t hi_bits, int both_signs, uint64_t* counts, uint32_t* example);
+/* The rank bookkeeping of rl_app_run for RlAppConfig{device, devices, n_devices} -- which device each rank renders on (its RNG
+ * stream is config.stream + rank), the first rank on the same device (ranks sharing a GPU are added onto it), the rank's place in
+ * the RCCL communicator (one per DISTINCT device in order of first appearance, so rank 0 is the root; -1: none) and the
+ * communicator's size (0: a run on one device needs none).  Host arithmetic only: callable without a GPU.  Arrays of
+ * max(n_devices, 1) entries. */
+int rl_debug_app_rank_plan(int device, const int* devices, uint32_t n_devices, int* rank_device, int* leader, int* comm_rank,
+                           uint32_t* n_communicator_ranks);
 /* Blocking render calls share launches (see rl_trace_unit_render).  out[k], k = 1..256: launches on `device` that
  * carried k calls since the library was loaded (257 counters, out[0] unused).  Waits for running ones to end. */
 int rl_debug_batch_histogram(int device, uint64_t* out);

@@ -374,15 +374,16 @@ class TaskScheduler(_Handle):
 
 def app_run(width, height, max_batches, concurrency=1, device=0, photons_per_batch=NUMBER_OF_PHOTONS, seed=1, stream=0,
             scene=SCENE_DEMO, scene_param=0, tonemap_interval_ms=30000, fused=False, output_ppm=None, checkpoint=None,
-            resume=False, verbose=False, sleep_us=0, first_batch=0, devices=None, blocking_trace=False):
+            resume=False, verbose=False, sleep_us=0, first_batch=0, devices=None, blocking_trace=False, threads=0):
     """App::new + worker loops (app.rs:54-111) until `max_batches` trace tasks are done, on one GPU or, with
     `devices` = a list of device indices (repeats allowed), on one rank per entry with the plot buffers summed
-    onto rank 0 at every gather.  Returns (rgb image as (H, W, 3) uint8, stats dict)."""
+    onto rank 0 at every gather.  `concurrency` sizes the scheduler's pools, `threads` (0 = concurrency) the host worker pool.
+    Returns (rgb image as (H, W, 3) uint8, stats dict)."""
     dev_arr = (C.c_int * len(devices))(*devices) if devices else None
     cfg = RlAppConfig(width, height, device, concurrency, photons_per_batch, seed, stream, scene, scene_param, max_batches,
                       tonemap_interval_ms, int(fused), output_ppm.encode() if output_ppm else None,
                       checkpoint.encode() if checkpoint else None, int(resume), int(verbose), sleep_us, first_batch,
-                      len(devices) if devices else 0, int(blocking_trace), dev_arr)
+                      len(devices) if devices else 0, int(blocking_trace), dev_arr, int(threads))
     stats = RlAppStats()
     rgb = np.zeros((height, width, 3), dtype=np.uint8)
     check(lib.rl_app_run(C.byref(cfg), C.byref(stats), rgb.ctypes.data_as(C.c_void_p)))
@@ -424,6 +425,16 @@ def math_sweep(fn, lo_bits, hi_bits, both_signs=False, device=0):
     check(lib.rl_debug_math_sweep(device, {"sqrt_short": 16, "recip_short": 17, "div200_short": 18}[fn], int(lo_bits), int(hi_bits),
                                   1 if both_signs else 0, counts, C.byref(example)))
     return int(counts[0]), int(counts[1]), int(example.value)
+
+
+def app_rank_plan(devices=None, device=0):
+    """rl_debug_app_rank_plan: (rank_device, leader, comm_rank, communicator size) of rl_app_run for `devices` (no GPU needed)."""
+    n = len(devices) if devices else 0
+    m = max(n, 1)
+    dev = (C.c_int * n)(*devices) if n else None
+    rd, ld, cr, size = (C.c_int * m)(), (C.c_int * m)(), (C.c_int * m)(), C.c_uint32(0)
+    check(lib.rl_debug_app_rank_plan(device, dev, n, rd, ld, cr, C.byref(size)))
+    return list(rd), list(ld), list(cr), int(size.value)
 
 
 def prism_probe(scene, prism, rays):

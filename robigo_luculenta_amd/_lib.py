@@ -53,7 +53,7 @@ class RlAppConfig(C.Structure):
                 ("builtin_scene", C.c_int), ("builtin_param", C.c_int), ("max_batches", C.c_uint64),
                 ("tonemap_interval_ms", C.c_int64), ("fused", C.c_int), ("output_ppm", C.c_char_p),
                 ("checkpoint", C.c_char_p), ("resume", C.c_int), ("verbose", C.c_int), ("sleep_us", C.c_uint32),
-                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("blocking_trace", C.c_int), ("devices", C.POINTER(C.c_int))]
+                ("first_batch", C.c_uint64), ("n_devices", C.c_uint32), ("blocking_trace", C.c_int), ("devices", C.POINTER(C.c_int)), ("threads", C.c_uint32)]
 
 
 class RlAppStats(C.Structure):
@@ -132,6 +132,7 @@ SIGNATURES = {
 DEBUG_SIGNATURES = {
     "rl_debug_math_probe": (_i, [_i, _i, _vp, _vp, _u32]),
     "rl_debug_math_sweep": (_i, [_i, _i, _u32, _u32, _i, _vp, _vp]),
+    "rl_debug_app_rank_plan": (_i, [_i, _vp, _u32, _vp, _vp, _vp, C.POINTER(_u32)]),
     "rl_debug_batch_histogram": (_i, [_i, _vp]),
     "rl_debug_variant_launches": (_i, [_vp]),
     "rl_debug_prism_probe": (_i, [_vp, _u32, _vp, _u32, _vp]),

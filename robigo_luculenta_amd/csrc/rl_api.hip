@@ -118,7 +118,6 @@ struct RlTraceUnit {
     uint32_t id, width, height, n_photons;
     RlMappedPhoton* photons;
     unsigned long long* queue; // 3 counters, see rl_trace_kernel
-    float* emit_queues = nullptr; // RL_EMIT_GLOBAL builds: one emitter queue per wave of the largest grid a launch of this unit can have
     hipStream_t stream;
     hipEvent_t rendered; // recorded on `stream` after everything that fills this unit's photons
     int fetch;
@@ -226,16 +225,6 @@ int stage_of(const RlScene* scene, int fetch, size_t scratch_bytes, size_t* byte
     return RL_STAGE_NONE;
 }
 
-// RL_EMIT_GLOBAL builds: the emitter queues of a fused launch, one per wave of its grid (at most 32 waves per CU), allocated on first use.
-int emit_queues_for(float** q, int cu_count) {
-#if RL_EMIT_GLOBAL
-    if (!*q) RL_HIP(hipMalloc((void**)q, (size_t)cu_count * 32u * RL_EMIT_QUEUE_FLOATS * sizeof(float)));
-#else
-    (void)q; (void)cu_count;
-#endif
-    return RL_OK;
-}
-
 // One launch of the trace kernel on u's stream: n_paths paths from first_path on, into `photons` (un-fused) or splatted
 // into plot_unit's buffer (fused).
 int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, RlPlotUnit* plot_unit, uint64_t seed,
@@ -295,11 +284,6 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
         RL_HIP(hipStreamWaitEvent(u->stream, plot_unit->tail, 0));
     }
     RL_HIP(hipMemsetAsync(u->queue, 0, sizeof(unsigned long long), u->stream));
-    if (fused) { // (a fused launch writes no photons: RL_EMIT_GLOBAL builds hand it the waves' emitter queues through that argument)
-        const int rc = emit_queues_for(&u->emit_queues, u->cu_count);
-        if (rc != RL_OK) return rc;
-        photons = (RlMappedPhoton*)u->emit_queues;
-    }
     RL_HIP(hipEventRecord(ep.start, u->stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(RL_TRACE_BLOCK), dyn, u->stream, scene->blob, scene->lay, job, photons,
                        plot, u->queue, (const RlJobEntry*)nullptr, (RlOpenDev*)nullptr, (RlOpenCtl*)nullptr);
@@ -588,7 +572,6 @@ int rl_trace_unit_destroy(RlTraceUnit* u) {
     if (u->stream) (void)hipStreamDestroy(u->stream);
     if (u->rendered) (void)hipEventDestroy(u->rendered);
     if (u->photons) (void)hipFree(u->photons);
-    if (u->emit_queues) (void)hipFree(u->emit_queues);
     if (u->queue) (void)hipFree(u->queue);
     delete u;
     return RL_OK;
@@ -627,7 +610,6 @@ struct Session {
     RlOpenCtl* ctl = nullptr;     // pinned, coherent host memory
     RlOpenCtl* ctl_dev = nullptr; // the same memory as the device addresses it
     unsigned long long* counters = nullptr; // [unused, segments, paths] of the running kernel
-    float* emit_queues = nullptr;           // RL_EMIT_GLOBAL builds: the running kernel's emitter queues
     hipEvent_t start = nullptr, stop = nullptr;
     bool launched = false; // a kernel was launched and its counters are not harvested yet
     bool open = false;     // the host may still try to append
@@ -773,10 +755,9 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     x.n = 1;
     RL_HIP(hipMemsetAsync(x.od, 0, sizeof(RlOpenDev), x.stream));
     RL_HIP(hipMemsetAsync(x.counters, 0, 3 * sizeof(unsigned long long), x.stream));
-    if (fused && (rc = emit_queues_for(&x.emit_queues, u->cu_count)) != RL_OK) return rc;
     RL_HIP(hipEventRecord(x.start, x.stream));
     hipLaunchKernelGGL(kernel, dim3((unsigned)(u->cu_count * per_cu)), dim3(RL_TRACE_BLOCK), dyn, x.stream, scene->blob, scene->lay, job,
-                       (RlMappedPhoton*)(fused ? x.emit_queues : nullptr), (float*)nullptr, x.counters, (const RlJobEntry*)x.od->jobs, x.od, x.ctl_dev);
+                       (RlMappedPhoton*)nullptr, (float*)nullptr, x.counters, (const RlJobEntry*)x.od->jobs, x.od, x.ctl_dev);
     RL_HIP(hipGetLastError());
     RL_HIP(hipEventRecord(x.stop, x.stream));
     x.launched = true;

@@ -393,6 +393,29 @@ void log_completed(const AppState& a, const RlTask& t) { // task_scheduler.rs:24
     (void)a;
 }
 
+// Who is who when one process drives several ranks, as a function a test can call without a GPU (rl_debug_app_rank_plan):
+// rank r renders on rank_device[r] with RNG stream `stream + r`; leader[r] is the first rank on the same device (ranks that share a GPU
+// are summed onto it with rl_plot_unit_add before anything crosses xGMI); comm_rank[r] is the rank's place in the RCCL communicator --
+// one per DISTINCT device, in order of first appearance, so rank 0's device is communicator rank 0, the root of every reduce -- or -1
+// for a rank that has none (not its device's leader, or a run on one device).  Returns the distinct devices in communicator order.
+std::vector<int> plan_ranks(int device, const int* devices, uint32_t n_devices, int* rank_device, int* leader, int* comm_rank) {
+    const uint32_t n_ranks = n_devices > 1 ? n_devices : 1;
+    std::vector<int> distinct;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        rank_device[r] = n_devices > 1 ? (devices ? devices[r] : device + (int)r) : device;
+        leader[r] = (int)r;
+        for (uint32_t q = 0; q < r; ++q)
+            if (rank_device[q] == rank_device[r]) {
+                leader[r] = leader[q];
+                break;
+            }
+        if (leader[r] == (int)r) distinct.push_back(rank_device[r]);
+    }
+    size_t next = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) comm_rank[r] = (distinct.size() > 1 && leader[r] == (int)r) ? (int)next++ : -1;
+    return distinct;
+}
+
 // App::start_worker's loop (app.rs:92-111), ending when the batch budget is exhausted.
 void worker(AppState* ap) {
     AppState& a = *ap;
@@ -459,26 +482,16 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
     // The ranks: one per listed device (a device may be listed more than once: several RNG streams on one GPU).
     const uint32_t n_ranks = config->n_devices > 1 ? config->n_devices : 1;
     a.ranks.resize(n_ranks);
-    std::vector<int> distinct;
-    for (uint32_t r = 0; r < n_ranks; ++r) {
-        Rank& k = a.ranks[r];
-        k.device = config->n_devices > 1 ? (config->devices ? config->devices[r] : config->device + (int)r) : config->device;
-        k.leader = (int)r;
-        for (uint32_t q = 0; q < r; ++q)
-            if (a.ranks[q].device == k.device) {
-                k.leader = a.ranks[q].leader;
-                break;
-            }
-        if (k.leader == (int)r) distinct.push_back(k.device);
-    }
+    std::vector<int> rank_device(n_ranks), leader(n_ranks), comm_rank(n_ranks);
+    const std::vector<int> distinct = plan_ranks(config->device, config->devices, config->n_devices, rank_device.data(), leader.data(), comm_rank.data());
+    for (uint32_t r = 0; r < n_ranks; ++r) a.ranks[r].device = rank_device[r], a.ranks[r].leader = leader[r];
     a.use_rccl = distinct.size() > 1;
     a.distinct_devices = distinct.size() == n_ranks;
     if (rc == RL_OK && a.use_rccl) {
         std::vector<RlComm*> comms(distinct.size(), nullptr);
         rc = rl_comm_init_all(distinct.data(), (int)distinct.size(), comms.data()); // rank 0's device is distinct[0] = comm rank 0
-        size_t next = 0;
         for (uint32_t r = 0; r < n_ranks; ++r)
-            if (a.ranks[r].leader == (int)r) a.ranks[r].comm = comms[next++];
+            if (comm_rank[r] >= 0) a.ranks[r].comm = comms[(size_t)comm_rank[r]];
     }
 
     std::vector<RlObjectDesc> objects;
@@ -527,7 +540,9 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
     if (rc == RL_OK) {
         a.t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> pool;
-        for (uint32_t i = 0; i < config->concurrency; ++i) pool.emplace_back(worker, &a); // app.rs:66-70
+        // app.rs:66-70 starts one thread per unit of scheduler depth; here the two are separate knobs (RlAppConfig::threads)
+        const uint32_t n_threads = config->threads ? (config->threads < config->concurrency ? config->threads : config->concurrency) : config->concurrency;
+        for (uint32_t i = 0; i < n_threads; ++i) pool.emplace_back(worker, &a);
         for (std::thread& t : pool) t.join();
         rc = a.error.load();
     }
@@ -601,4 +616,16 @@ extern "C" int rl_app_run(const RlAppConfig* config, RlAppStats* stats, uint8_t*
     rl_scheduler_destroy(a.scheduler);
     if (rc != RL_OK && !message.empty()) rl_internal_set_last_error(message); // the failing call may have run on a worker thread
     return rc;
+}
+
+// Diagnostics (robigo_luculenta_debug.h): the rank bookkeeping of rl_app_run for a device list, no GPU needed.
+extern "C" int rl_debug_app_rank_plan(int device, const int* devices, uint32_t n_devices, int* rank_device, int* leader, int* comm_rank,
+                                      uint32_t* n_communicator_ranks) {
+    if (!rank_device || !leader || !comm_rank || !n_communicator_ranks) {
+        rl_internal_set_last_error("rl_debug_app_rank_plan: null output");
+        return RL_E_INVALID;
+    }
+    const std::vector<int> distinct = plan_ranks(device, devices, n_devices, rank_device, leader, comm_rank);
+    *n_communicator_ranks = distinct.size() > 1 ? (uint32_t)distinct.size() : 0u;
+    return RL_OK;
 }

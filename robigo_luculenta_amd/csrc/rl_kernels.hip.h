@@ -64,11 +64,14 @@
 #ifndef RL_W_PR
 #define RL_W_PR 1 // prism rounds: the first plane's two records likewise
 #endif
+#ifndef RL_EMIT_MAX_AGE
+#define RL_EMIT_MAX_AGE 8u
+#endif
+#ifndef RL_OPEN_FULL
+#define RL_OPEN_FULL 1
+#endif
 #ifndef RL_SMALL_UNROLL
 #define RL_SMALL_UNROLL 1
-#endif
-#ifndef RL_EMIT_GLOBAL
-#define RL_EMIT_GLOBAL 0 // 1: the emitter queue of plain fused launches lives in global memory (five waves per SIMD: LDS per wave is what is short)
 #endif
 #ifndef RL_MEMBER_FENCE
 #define RL_MEMBER_FENCE (RL_TRACE_WPS > 4)
@@ -350,19 +353,9 @@ struct RlWaveScratch {
     float stash[10][64];
     // Fused mode: paths that ended on an emitter wait here (sx, sy, wavelength, intensity, emitter object)
     // until (about) 64 of them can be evaluated and splatted with a full exec mask.
-#if !RL_EMIT_GLOBAL
     float emit[5][64];
-#else
-    // (RL_EMIT_GLOBAL: the plain fused launches keep this queue in global memory -- RL_EMIT_QUEUE_FLOATS below -- and the wave's scratch is
-    // 1,280 bytes smaller, padded to the next multiple of 512)
-    float pad_[64]; // 6,912 -> 7,168 bytes
-#endif
 };
-static_assert(sizeof(RlWaveScratch) % 512 == 0, "rl_scan_wave's ring addressing wants the wave's scratch 512-byte aligned");
-// RL_EMIT_GLOBAL: one emitter queue per wave of the grid, in device memory: 5 rows of 64 floats (the layout of RlWaveScratch::emit).
-// A path ends on a light ~2 times per wave iteration: five fire-and-forget global stores instead of five LDS writes, read back once
-// per ~30 iterations when a batch runs (behind an s_waitcnt vmcnt(0), with loads that bypass the L1).
-#define RL_EMIT_QUEUE_FLOATS 320u
+static_assert(sizeof(RlWaveScratch) == 8192, "rl_scan_wave's ring addressing wants the wave's scratch 512-byte aligned");
 
 typedef float RlV4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) RlV4 RlLdsV4;
@@ -424,7 +417,7 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S, bool SPHERES_IN_LDS>
+template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S, bool SPHERES_IN_LDS, bool TABLES_IN_LDS>
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, uint32_t small_ordered, float sv_cull_cmax2,
                                               uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
                                               uint32_t lane RL_TACC_PARAM) {
@@ -517,7 +510,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // between them when every paraboloid's object precedes every plane's (RlSceneLayout::small_ordered, the built-in scenes) --
     // two compares, two mask operations and a branch less per candidate than the general form, which other scenes take.
 #define RL_SMALL_PRIMITIVES(NEARER, NP, NL)                                                           \
-    _Pragma("unroll") for (uint32_t i = 0; i < (NP); ++i) {                                           \
+    for (uint32_t i = 0; i < (NP); ++i) {                                                             \
         const RlF4 r0 = sv.parabs[3 * i], r1 = sv.parabs[3 * i + 1], r2 = sv.parabs[3 * i + 2];       \
         if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* records in LDS: 16-byte loads (rl_hex_prism_fast), a 12-byte LDS read takes twice the LDS time */ \
         const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);                  \
@@ -527,7 +520,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             best.obj = obj;                                                                           \
         }                                                                                             \
     }                                                                                                 \
-    _Pragma("unroll") for (uint32_t i = 0; i < (NL); ++i) {                                           \
+    for (uint32_t i = 0; i < (NL); ++i) {                                                             \
         const RlF4 r0 = sv.planes[2 * i], r1 = sv.planes[2 * i + 1];                                  \
         float dn;                                                                                     \
         const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);                              \
@@ -546,7 +539,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // (three paraboloids and three planes / circles -- the room of every built-in scene, app.rs:166-236 -- get straight-line code: the
     // records' addresses are immediates, their loads can be requested ahead of the arithmetic that is in the way, and the two loops'
     // counters and branches go; any other count takes the loops)
-    if (RL_SMALL_UNROLL && small_ordered != 0u && n_parabs == 3u && n_planes == 3u) {
+    if (RL_SMALL_UNROLL && TABLES_IN_LDS && small_ordered != 0u && n_parabs == 3u && n_planes == 3u) { // (from global memory the records are scalar loads: two objects in flight cost 24 scalar registers the global-fetch variants do not have)
         // One object's records in flight behind the previous object's arithmetic: six exposed LDS round trips become one.  (The
         // arithmetic has wave-uniform fallback branches -- short square root, one-division form -- so the scheduler, which works on
         // basic blocks, never moves a load up by itself; the fences keep the loads where they are written.)
@@ -1140,20 +1133,11 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     RlLdsU32* wg_seg = (RlLdsU32*)&wgp->seg[0];
     RlLdsU32* wg_flushed_at = (RlLdsU32*)&wgp->flushed_at;
     RlLdsU32* wg_poll = (RlLdsU32*)&wgp->poll[0];
-    constexpr bool EMITG = RL_EMIT_GLOBAL != 0; // (a build option: every fused launch of such a build, plain or open, gets its queues through `photons`)
-#if !RL_EMIT_GLOBAL
     RlLdsF32* emit = (RlLdsF32*)&ws->emit[0][0];
-    float* emit_g = nullptr;
-#else
-    RlLdsF32* emit = nullptr;
-    float* emit_g = (float*)photons + (size_t)(blockIdx.x * (RL_TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) * RL_EMIT_QUEUE_FLOATS; // (fused: `photons` carries the queues)
-#endif
     auto emit_put = [&](uint32_t row, uint32_t slot, float v) {
-        if (EMITG) emit_g[row * 64u + slot] = v;
-        else emit[row * 64u + slot] = v;
+        emit[row * 64u + slot] = v;
     };
     auto emit_get = [&](uint32_t row, uint32_t slot) -> float {
-        if (EMITG) return rl_u2f(__hip_atomic_load((const uint32_t*)emit_g + row * 64u + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         return emit[row * 64u + slot];
     };
     if (OPEN) {
@@ -1211,7 +1195,8 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
     };
     uint32_t e_head = 0, e_tail = 0; // wave-uniform ring indices of the emitter queue
     bool ended_on_emitter = false, ended_now = false;
-    uint32_t emit_obj = 0;
+    uint32_t emit_obj = 0, emit_idx = 0;
+    uint32_t emit_age = 0; // wave-uniform: iterations since the queue last ran (open un-fused launches)
 #ifdef RL_STATS
     unsigned long long st[RL_ST_COUNT];
     for (int k = 0; k < RL_ST_COUNT; ++k) st[k] = 0;
@@ -1225,8 +1210,43 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         RL_STAT(RL_ST_EMIT_LANES, count);
         if (OPEN && emit_pend != 0) settle(); // (a second batch in one iteration -- 64 paths ending at once: count the first before its tags go)
         rl_wave_sync();
-        if (EMITG) asm volatile("s_waitcnt vmcnt(0) ; the queue's stores have reached the L2" ::: "memory");
-        if (lane < count) {
+        if (!FUSED) {
+            // Un-fused: the batch's paths ended on a light; their records are written HERE, with the emitter term (f64 Planck)
+            // evaluated for the whole batch at once instead of in the iteration the path ended in, for the two lanes it ended
+            // in (round 6: ~120 instructions per iteration at 3 % of the lanes).  Queue rows: 0 = the photon's index in its
+            // unit, 3 = the path's intensity, 4 = the emitter object (| call << 24 in open launches).  x, y and the wavelength are
+            // the path's first draws again (trace_unit.rs:152-158 as rl_begin_path has it): same words, same conversions.
+            uint32_t idx = 0, tagged = 0;
+            float value = 0.0f;
+            RlMappedPhoton* dst_base = photons;
+            if (lane < count) {
+                const uint32_t slot = (e_head + lane) & 63u;
+                idx = rl_f2u(emit_get(0, slot));
+                tagged = rl_f2u(emit_get(4, slot));
+                if (OPEN) ((RlLdsU32*)ws->ring_b)[lane] = tagged; // (settle() counts these paths per call: see the fused branch)
+                uint64_t first = job.first_path;
+                if (OPEN) {
+                    const RlJobEntry e = jobs[tagged >> 24];
+                    first = e.first_path, dst_base = (RlMappedPhoton*)e.target;
+                }
+                const RlRngBlock b0 = rl_rng_block(job.seed, job.stream, first + idx, 0);
+                RlMappedPhoton ph;
+                ph.wavelength = rl_get_wavelength(b0.w[0]);
+                ph.x = rl_get_bi_unit(b0.w[1]);
+                ph.y = rl_get_bi_unit(b0.w[2]) / job.aspect_ratio;
+                value = rl_emission(sv, emit_get(3, slot), ph.wavelength, OPEN ? (tagged & 0xffffffu) : tagged);
+                ph.probability = value;
+                if (OPEN) { // write-through: the reader is a kernel launched while this one still runs
+                    uint32_t* dst = (uint32_t*)&dst_base[idx];
+                    __hip_atomic_store(dst + 0, rl_f2u(ph.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 1, rl_f2u(ph.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 2, rl_f2u(ph.probability), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(dst + 3, rl_f2u(ph.wavelength), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    dst_base[idx] = ph;
+                }
+            }
+        } else if (lane < count) {
             const uint32_t slot = (e_head + lane) & 63u;
             const float sx = emit_get(0, slot), sy = emit_get(1, slot), wavelength = emit_get(2, slot);
             const uint32_t tagged = rl_f2u(emit_get(4, slot));
@@ -1566,7 +1586,7 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             // an open launch with nothing to hand out at the moment: report what is finished (the host may be waiting
             // for exactly that before it sends more) and look again
             settle();
-            if (FUSED && e_tail != e_head) {
+            if (e_tail != e_head) {
                 process_emitted(e_tail - e_head);
                 e_head = e_tail;
                 settle();
@@ -1579,7 +1599,10 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         // instantiation with both LDS and 64-bit global addresses to hold: unrolled it spills two vector registers to scratch)
         // (... and their children's bounds requested ahead of the fetch wherever that leaves the instantiation spill-free: not in the
         // open launches of a tables-only scene, 64-bit global addresses again)
-        const RlHit hit = rl_scan_wave<CYL, !OPEN && RL_LEAN_SPLIT, STAGE != RL_STAGE_NONE && !(FUSED && OPEN), STAGE != RL_STAGE_NONE && !(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) && RL_W_S && RL_LEAN_HOIST, STAGE == RL_STAGE_ALL>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
+        // (round 6: the Compound tree's lean form freed ~15 registers, and the open launches of a scene that is staged whole now take
+        // every one of these options inside their 120 registers; the tables-only and global-fetch open variants still do not)
+        constexpr bool FULL = !OPEN || (RL_OPEN_FULL && STAGE == RL_STAGE_ALL && (FUSED || !CYL)); // (the un-fused open variant of a scene with prism cylinders spills one scalar register with them)
+        const RlHit hit = rl_scan_wave<CYL, FULL && RL_LEAN_SPLIT, STAGE != RL_STAGE_NONE && (!(FUSED && OPEN) || FULL), STAGE != RL_STAGE_NONE && (!(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) || FULL) && RL_W_S && RL_LEAN_HOIST, STAGE == RL_STAGE_ALL, STAGE != RL_STAGE_NONE>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
                                        p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
@@ -1616,8 +1639,9 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 active = false;
                 p.direction = rl_f3(0.0f, 0.0f, 0.0f);
                 paths_done += 1;
-                if (!FUSED) { // the record is written here, the emitter term evaluated in place
-                    if (status == RL_PATH_ENDED_ON_EMITTER) value = rl_emission(sv, p.intensity, p.wavelength, emitter);
+                ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
+                emit_obj = OPEN ? (emitter | (my_job << 24)) : emitter; // open launches: the call, i.e. the target
+                if (!FUSED && !ended_on_emitter) { // The Void, roulette: the record (probability 0) is written here
                     RlMappedPhoton ph;
                     ph.x = p.sx;
                     ph.y = p.sy;
@@ -1633,10 +1657,8 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                     } else {
                         photons[my_path - job.first_path] = ph;
                     }
-                } else {
-                    ended_on_emitter = status == RL_PATH_ENDED_ON_EMITTER; // only these can contribute (trace_unit.rs:94-101,131)
-                    emit_obj = OPEN ? (emitter | (my_job << 24)) : emitter; // open launches: the call, i.e. the plot buffer
                 }
+                if (!FUSED && ended_on_emitter) emit_idx = (uint32_t)(my_path - (OPEN ? jobs[my_job].first_path : job.first_path));
                 if (OPEN) { // trace_unit.rs:92-131: the Void and a light end the path in the scan's iteration, roulette after the bounce
                     ended_now = true;
                     __hip_atomic_fetch_add(wg_seg + my_job, p.bounce + ((hit.obj == RL_HIT_NONE || status == RL_PATH_ENDED_ON_EMITTER) ? 1u : 0u),
@@ -1645,15 +1667,15 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
             }
         }
         if (OPEN) {
-            // a path that ended on a light is finished when it is splatted (process_emitted), every other one now
-            pend_me = ended_now && !(FUSED && ended_on_emitter);
+            // a path that ended on a light is finished when it is splatted / its record is written (process_emitted), every other one now
+            pend_me = ended_now && !ended_on_emitter;
             pend_any = __builtin_amdgcn_ballot_w64(pend_me) != 0;
             ended_now = false;
         }
         RL_T1(RL_ST_T_SHADE, t_shade);
         RL_T0(t_emit);
-        if (FUSED) {
-            // ---- fused splat (plot_unit.rs:56-95), deferred: queue the paths that ended on a light ----
+        {
+            // ---- fused splat (plot_unit.rs:56-95) / un-fused record of a contributing path, deferred: queue the paths that ended on a light ----
             const uint64_t m = __builtin_amdgcn_ballot_w64(ended_on_emitter);
             if (m != 0) {
                 // The queue holds 64 paths.  A batch runs when it is exactly full -- or, before these paths would overflow it,
@@ -1665,9 +1687,13 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                 }
                 if (ended_on_emitter) {
                     const uint32_t slot = rl_mbcnt_from(m, e_tail) & 63u;
-                    emit_put(0, slot, p.sx);
-                    emit_put(1, slot, p.sy);
-                    emit_put(2, slot, p.wavelength);
+                    if (FUSED) {
+                        emit_put(0, slot, p.sx);
+                        emit_put(1, slot, p.sy);
+                        emit_put(2, slot, p.wavelength);
+                    } else {
+                        emit_put(0, slot, rl_u2f(emit_idx));
+                    }
                     emit_put(3, slot, p.intensity);
                     emit_put(4, slot, rl_u2f(emit_obj));
                     ended_on_emitter = false;
@@ -1678,10 +1704,21 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
                     e_head += 64u;
                 }
             }
+            // Open un-fused launches: a call is complete -- and its caller, who may be BLOCKED in TraceUnit::render, released -- only
+            // when its last queued record is written, and a queue fills in ~30 iterations (half a millisecond); a batch that has
+            // waited RL_EMIT_MAX_AGE iterations runs with what it has.
+            if (OPEN && !FUSED) {
+                emit_age = e_tail != e_head ? emit_age + 1u : 0u;
+                if (RL_UNLIKELY(emit_age >= RL_EMIT_MAX_AGE)) {
+                    process_emitted(e_tail - e_head);
+                    e_head = e_tail;
+                    emit_age = 0;
+                }
+            }
         }
         RL_T1(RL_ST_T_EMIT, t_emit);
     }
-    if (FUSED && e_tail != e_head) process_emitted(e_tail - e_head);
+    if (e_tail != e_head) process_emitted(e_tail - e_head);
     if (OPEN) {
         settle();
         flush(0u);
