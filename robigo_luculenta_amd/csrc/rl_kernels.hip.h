@@ -1194,8 +1194,6 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         }
     };
     uint32_t e_head = 0, e_tail = 0; // wave-uniform ring indices of the emitter queue
-    bool ended_on_emitter = false, ended_now = false;
-    uint32_t emit_obj = 0, emit_idx = 0;
     uint32_t emit_age = 0; // wave-uniform: iterations since the queue last ran (open un-fused launches)
 #ifdef RL_STATS
     unsigned long long st[RL_ST_COUNT];
@@ -1630,6 +1628,10 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         }
 #endif
         RL_T0(t_shade);
+        // (declared per iteration: every one of these is set and consumed between here and the queue push below; at function scope
+        // they were loop-carried values the compiler kept in registers across the scan)
+        bool ended_on_emitter = false, ended_now = false;
+        uint32_t emit_obj = 0, emit_idx = 0;
         if (active) {
             segments += 1;
             float value;
