@@ -417,16 +417,18 @@ def measure(R, config, fetch, rank, launches, batches_per_launch, warm_launches,
                                      "frac": achieved / PEAK_FP32_VECTOR_TFLOPS}}
 
 
-def measure_app(R, fused, workers, device, batches=8192):
+def measure_app(R, fused, threads, device, batches=8192, depth=64):
     """The drop-in at the reference's own task size: rl_app_run (TaskScheduler + worker pool, csrc/rl_app.cpp) with Trace
-    tasks of 524,288 paths (trace_unit.rs:67) and as many workers as the host has cores (app.rs:55), at 1280x720."""
-    rgb, st = R.app_run(1280, 720, batches, concurrency=workers, photons_per_batch=BATCH, fused=fused, verbose=False, device=device)
+    tasks of 524,288 paths (trace_unit.rs:67) at 1280x720.  Round 6: the scheduler's depth (RlAppConfig::concurrency: 3 x depth
+    trace units in circulation, task_scheduler.rs:95-96) is no longer the host thread count (RlAppConfig::threads) -- a few host
+    threads keep a deep pool of begun renders in flight (profiles/r06_app.txt: depth x threads)."""
+    rgb, st = R.app_run(1280, 720, batches, concurrency=depth, threads=threads, photons_per_batch=BATCH, fused=fused, verbose=False, device=device)
     return {"config": "app-720p-%s" % ("fused" if fused else "unfused"),
             "workload": "rl_app_run: built-in demo scene, 1280x720, %d batches of %d paths through the scheduler's Trace / Plot / Gather "
-                        "tasks, %d workers, %s; includes the final tonemap"
-                        % (batches, BATCH, workers, "Trace + Plot fused at plot time" if fused else "separate Trace and Plot tasks as in the reference"),
+                        "tasks, scheduler depth %d, %d host threads, %s; includes the final tonemap"
+                        % (batches, BATCH, depth, threads, "Trace + Plot fused at plot time" if fused else "separate Trace and Plot tasks as in the reference"),
             "value": st["segments"] / st["seconds"] / 1e6, "unit": "Mrays/s", "mpaths_per_s": st["paths"] / st["seconds"] / 1e6,
-            "batches_per_s": st["paths"] / BATCH / st["seconds"], "workers": workers, "seconds": st["seconds"]}
+            "batches_per_s": st["paths"] / BATCH / st["seconds"], "workers": threads, "depth": depth, "seconds": st["seconds"]}
 
 
 def spawn_ranks(args):
@@ -801,7 +803,7 @@ def main():
         }
         if world == 1 and not args.no_others:
             out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]
-            workers = max(1, min(usable_cores(), 85))
+            workers = max(1, min(usable_cores(), 4))
             out["config"]["others"] += [measure_app(R, fused, workers, device) for fused in (False, True)]
         if world == 1 and not args.no_live_counters and not os.environ.get("RL_BENCH_LIVE_CHILD"):
             live = executed_live(args, executed)

@@ -207,6 +207,8 @@ TraceKernel trace_kernel_variant(int stage, bool fused, bool open, bool cyl) {
     };
     return table[index];
 }
+// Ring T of rl_scan_wave: 512 bytes per wave in front of the scratch blocks, for scenes whose cull table has a third level.
+size_t ring_t_bytes(const RlScene* scene) { return scene->lay.n_cluster_supers != 0u ? (size_t)(RL_TRACE_BLOCK / 64) * 512u : 0u; }
 // What a launch stages in LDS beside `scratch_bytes` of per-wave scratch: the whole scene where it fits, its tables where
 // those do, nothing otherwise (or when the unit was created with RL_FETCH_GLOBAL); *bytes = the staged size.
 int stage_of(const RlScene* scene, int fetch, size_t scratch_bytes, size_t* bytes) {
@@ -214,7 +216,7 @@ int stage_of(const RlScene* scene, int fetch, size_t scratch_bytes, size_t* byte
     if (fetch != RL_FETCH_LDS) return RL_STAGE_NONE;
     // (what is staged is rounded up to 512 bytes: the waves' scratch behind it is 512-byte aligned, rl_trace_body)
     const size_t all = (scene->staged_bytes + 511) & ~(size_t)511, tables = (scene->tables_bytes + 511) & ~(size_t)511;
-    if (all + scratch_bytes <= 160 * 1024) {
+    if (scene->lay.n_cluster_supers == 0u && all + scratch_bytes <= 160 * 1024) { // (a table with a third level: the whole-scene variants do not carry its code)
         *bytes = all;
         return RL_STAGE_ALL;
     }
@@ -248,7 +250,7 @@ int launch_trace(RlTraceUnit* u, const RlScene* scene, RlMappedPhoton* photons, 
     job.hm1 = (float)(int)u->height - 1.0f;
 
     // One workgroup of RL_TRACE_BLOCK threads per CU: [scene blob][per-wave scratch] in dynamic LDS.
-    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch);
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + ring_t_bytes(scene);
     size_t blob_bytes = 0;
     const int stage = stage_of(scene, u->fetch, scratch_bytes, &blob_bytes);
     const bool fused = plot != nullptr;
@@ -472,6 +474,8 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.cluster_k = fs.cluster_k;
     lay.n_cluster_groups = fs.n_cluster_groups;
     lay.n_prism_groups = fs.n_prism_groups;
+    lay.n_cluster_supers = fs.n_cluster_supers;
+    lay.super_g = fs.super_g;
     lay.n_planes = (uint32_t)(fs.planes.size() / 2);
     lay.n_parabs = (uint32_t)(fs.parabs.size() / 3);
     lay.n_prisms = (uint32_t)(fs.prisms.size() / RL_PRISM_STRIDE);
@@ -733,7 +737,7 @@ int session_start(DeviceSessions* d, Session& x, RlTraceUnit* u, const RlScene* 
     job.reserved = 0;
     job.wm1 = (float)(int)u->width - 1.0f;
     job.hm1 = (float)(int)u->height - 1.0f;
-    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg);
+    const size_t scratch_bytes = (RL_TRACE_BLOCK / 64) * sizeof(RlWaveScratch) + sizeof(RlOpenWg) + ring_t_bytes(scene);
     size_t blob_bytes = 0;
     const int stage = stage_of(scene, u->fetch, scratch_bytes, &blob_bytes);
     auto kernel = trace_kernel_variant(stage, fused, true, scene->lay.prism_cylinders != 0u);

@@ -562,7 +562,16 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pr
     // not decided here: a ray nearly parallel to a face, a crossing at the origin (NaNs fail both compares)
     bool sure = (min_dn >= 1.52587890625e-05f * pr[2].w * d1) & (min_ta >= 1.0e-30f); // (& and | below: no branches, see rl_paraboloid_t)
     const uint32_t k_e = rl_f2u(t_in) & 7u, k_x = rl_f2u(t_out) & 7u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The entry and the exit plane's records, all four requested at once (round 6): plane k* below is one of the two, so its normal,
+    // its offset and its n.d are selected from these instead of loaded -- and waited for -- again once k* is known; 16-byte loads
+    // (the fourth components are operands of the empty statement: a 12-byte LDS read takes twice the LDS time).
+    const RlF4 rec_e = pr[2 * k_e], rec_x = pr[2 * k_x], off_e = pr[2 * k_e + 1], off_x = pr[2 * k_x + 1];
+    if (PIPELINED) asm volatile("" : : "v"(rec_e.w), "v"(rec_x.w), "v"(off_e.w), "v"(off_x.w));
+    const float dn_e = rl_dot(rl_xyz(rec_e), d), dn_x = rl_dot(rl_xyz(rec_x), d); // = dn[k_e], dn[k_x]
+#else
     const float dn_e = rl_dot(rl_xyz(pr[2 * k_e]), d), dn_x = rl_dot(rl_xyz(pr[2 * k_x]), d); // = dn[k_e], dn[k_x]
+#endif
     const bool from_outside = t_in > 0.0f;
     const float t0 = from_outside ? t_in : 0.0f;
     const bool reaches = t_out > t0;
@@ -587,9 +596,15 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pr
     const bool miss_sure = from_outside ? miss_a > delta_a : (!(t_first < INF) | (miss_b > delta_b));
     sure = sure & (reaches ? hit_sure : miss_sure);
     // the reference's own t for plane k* (geometry.rs:62)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const RlF3 n = rl_f3(from_outside ? rec_e.x : rec_x.x, from_outside ? rec_e.y : rec_x.y, from_outside ? rec_e.z : rec_x.z);
+    const RlF3 lo = rl_sub(o, rl_f3(from_outside ? off_e.x : off_x.x, from_outside ? off_e.y : off_x.y, from_outside ? off_e.z : off_x.z));
+    out->t = -rl_dot(n, lo) / (from_outside ? dn_e : dn_x); // (rl_dot(n, d) of the same operands: the same float)
+#else
     const RlF3 n = rl_xyz(pr[2 * k_star]);
     const RlF3 lo = rl_sub(o, rl_xyz(pr[2 * k_star + 1]));
     out->t = -rl_dot(n, lo) / rl_dot(n, d);
+#endif
     out->k = k_star;
     return !sure ? RL_PRISM_UNSURE : (reaches ? RL_PRISM_HIT : RL_PRISM_MISS);
 }

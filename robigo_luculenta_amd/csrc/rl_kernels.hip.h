@@ -73,6 +73,12 @@
 #ifndef RL_SMALL_UNROLL
 #define RL_SMALL_UNROLL 1
 #endif
+#ifndef RL_S_AHEAD2
+#define RL_S_AHEAD2 1 // ring-S rounds of a scene whose cull table is in global memory: two children's bounds requested ahead
+#endif
+#ifndef RL_MEMBER_AHEAD2
+#define RL_MEMBER_AHEAD2 0 // cluster-member rounds of a scene whose spheres are in global memory: two records requested ahead instead of one (measured: 4,539 objects -4.5 %, 5,019 random spheres +-0 -- the gathers are bound by the lines the L1 serves per cycle, not by latency)
+#endif
 #ifndef RL_MEMBER_FENCE
 #define RL_MEMBER_FENCE (RL_TRACE_WPS > 4)
 #endif
@@ -82,6 +88,9 @@
 #endif
 #ifndef RL_LEAN_HOIST
 #define RL_LEAN_HOIST (RL_TRACE_WPS <= 4)
+#endif
+#ifndef RL_PROGRESSIVE_FAR
+#define RL_PROGRESSIVE_FAR 1 // in the variants for scenes that are not staged whole (rl_scan_wave: SUPER): the rounds' far bound follows the merge keys -- the nearest hit found SO FAR in this scan -- not just the small primitives' hit
 #endif
 #define RL_CHUNK 256ull     // paths a wave takes from the global queue at a time (4 stash refills) in large launches
 
@@ -95,6 +104,7 @@ struct RlSceneLayout {
     uint32_t off_prism_cyl, prism_cylinders;   // RlFlatScene::prism_cyl (2 records per prism) and whether to test them
     uint32_t group_gc;                         // RlFlatScene::group_gc: clusters per group of the cull table
     uint32_t small_ordered;                    // the paraboloids' objects all precede the planes' and circles' (rl_scan_wave: one compare per candidate)
+    uint32_t n_cluster_supers, super_g;        // RlFlatScene: third level of the cull table (0: none); a scene that has one is never staged whole
     // Records [off_planes, off_objects) of the blob are the TABLES -- planes, paraboloids, prisms, the cull table, the camera:
     // everything a scan reads with wave-uniform addresses or once per (group, ray) / (prism, ray) pair, 10-40 KB whatever the
     // scene's size.  The spheres in front of them and the per-object arrays behind them grow with the scene: one too large for
@@ -346,6 +356,12 @@ struct RlWaveScratch {
     // now) and the object table (one record per object).
     float terms_d[64][4]; // {d.xyz, p}: two arrays of 16-byte slots rather than one of 32-byte ones -- a 16-byte gather is served
     float terms_m[64][4]; // {m.xyz, q}  in groups of 16 lanes, and 16-byte strides spread 16 owners over all 16 bank quads
+    // The far bound of the lane's ray: the distance of its nearest plane / circle / paraboloid hit (before the prisms: of its nearest
+    // hit) in the cull's units -- or, in the variants for scenes that are not staged whole (RL_PROGRESSIVE_FAR), RlCullRay::len alone:
+    // a round's far bound is then the distance of the nearest hit its owner has SO FAR -- the high word of the owner's merge key,
+    // which every sphere-tail round lowers -- times this, so that bounds behind a sphere an earlier round of the SAME scan found are
+    // culled like those behind the walls.  (Dense scenes: 5,000 random spheres 1.7 -> 3.6 Grays/s, 20,000: 0.41 -> 5.3; one LDS
+    // read and one product per round, -0.3 % on the built-in scene, which keeps the plain form.)
     float far[64];
     // Stash of 64 freshly generated camera rays (SoA): ox oy oz dx dy dz wavelength sx sy ior.  Refilled with all 64 lanes
     // busy; slot s holds path (stash_path0 + s) of the RNG stream, the first stash_valid slots hold a path at all
@@ -361,15 +377,18 @@ typedef float RlV4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) RlV4 RlLdsV4;
 typedef __attribute__((address_space(3))) float RlLdsF;
 // A lane's cull terms (and far bound) into its slot of the wave's scratch, once per scan ...
+template <bool PF = false>
 __device__ __forceinline__ void rl_store_cull_ray(RlWaveScratch* ws, uint32_t lane, const RlCullRay& cr, float far) {
     ((RlLdsV4*)&ws->terms_d[0][0])[lane] = (RlV4){cr.d.x, cr.d.y, cr.d.z, cr.p};
     ((RlLdsV4*)&ws->terms_m[0][0])[lane] = (RlV4){cr.m.x, cr.m.y, cr.m.z, cr.q};
-    ((RlLdsF*)&ws->far[0])[lane] = far;
+    ((RlLdsF*)&ws->far[0])[lane] = PF ? cr.len : far;
 }
 // ... and the OWNER lane's, for a round: two 16-byte gathers and a 4-byte one (the caller has passed a wave sync since the store).
+template <bool PF = false>
 __device__ __forceinline__ void rl_fetch_cull_ray(RlWaveScratch* ws, uint32_t owner, RlCullRay& r, float& r_far) {
     const RlV4 a = ((const RlLdsV4*)&ws->terms_d[0][0])[owner], b = ((const RlLdsV4*)&ws->terms_m[0][0])[owner];
     r_far = ((const RlLdsF*)&ws->far[0])[owner];
+    if (PF) r_far *= rl_u2f(((const RlLdsU32*)&ws->key[0])[2u * owner + 1u]); // (the caller has passed a wave sync since the key's last merge)
     r.d = rl_f3(a.x, a.y, a.z);
     r.p = a.w;
     r.m = rl_f3(b.x, b.y, b.z);
@@ -417,11 +436,12 @@ struct RlOpenWg {
 //     when one of its pairs is undecided, then min-merges.
 // Results are min-merged per owning ray as 64-bit (distance bits, object index) keys in LDS: exactly
 // scene.rs:51's strict `<` over objects in scan order, in any evaluation order.
-template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S, bool SPHERES_IN_LDS, bool TABLES_IN_LDS>
+template <bool CYL, bool SPLIT, bool UNROLL_S, bool HOIST_S, bool SPHERES_IN_LDS, bool TABLES_IN_LDS, bool SUPER>
 __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4* cull, const RlF4* prism_cyl, uint32_t group_gc, uint32_t small_ordered, float sv_cull_cmax2,
-                                              uint32_t n_cluster_groups, uint32_t n_prism_groups, RlF3 o, RlF3 dir, uint32_t idle_bit, RlWaveScratch* ws,
-                                              uint32_t lane RL_TACC_PARAM) {
+                                              uint32_t n_cluster_groups, uint32_t n_prism_groups, uint32_t n_cluster_supers, uint32_t super_g, RlLdsU32* ring_t, RlF3 o, RlF3 dir,
+                                              uint32_t idle_bit, RlWaveScratch* ws, uint32_t lane RL_TACC_PARAM) {
     // Explicit LDS address space: generic pointers here would become flat_* accesses.
+    constexpr bool PF = SUPER && RL_PROGRESSIVE_FAR;
     RlLdsU64* keys = (RlLdsU64*)ws->key;
     RlLdsU32* ring_a = (RlLdsU32*)ws->ring_a;
     RlLdsU32* ring_b = (RlLdsU32*)ws->ring_b;
@@ -485,6 +505,32 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const bool pass_ = (LHS) <= (RHS);                                                                              \
         const uint64_t m_ = __builtin_amdgcn_ballot_w64(pass_);                                                         \
         RL_RING_PUSH(RING, pass_, m_, TAIL, ENTRY)                                                                      \
+        TAIL += (uint32_t)__popcll(m_);                                                                                 \
+    }
+#endif
+    // ... and the same push into ring T (SUPER: the third level's (super, ray) pairs), which lives outside the wave's scratch -- 512 bytes
+    // per wave between the staged tables and the scratch blocks, 512-byte aligned like the rings inside
+    const uint32_t wt_addr = (uint32_t)(size_t)ring_t;
+    uint32_t rt_lim = 64u, rt_tail = 0;
+#if RL_PUSH_ASM && RL_PUSH_CMPX
+#define RL_LE_PUSH_T(LHS, RHS, TAIL, ENTRY)                                                                             \
+    {                                                                                                                   \
+        uint32_t slot_, n_;                                                                                             \
+        asm volatile("v_cmpx_le_f32_e32 vcc, %2, %3\n\ts_bcnt1_i32_b64 %1, vcc\n\ts_nop 0\n\t"                              \
+                     "v_mbcnt_lo_u32_b32 %0, vcc_lo, 0\n\tv_mbcnt_hi_u32_b32 %0, vcc_hi, %0\n\t"                            \
+                     "v_add_lshl_u32 %0, %0, %4, 2\n\tv_and_or_b32 %0, %0, %5, %6\n\tds_write_b32 %0, %7\n\t"               \
+                     "s_mov_b64 exec, -1"                                                                               \
+                     : "=&v"(slot_), "=&s"(n_)                                                                           \
+                     : "v"(LHS), "v"(RHS), "s"(TAIL), "s"(ring_mask), "v"(wt_addr), "v"(ENTRY)                           \
+                     : "vcc", "scc", "memory");                                                                         \
+        TAIL += n_;                                                                                                     \
+    }
+#else
+#define RL_LE_PUSH_T(LHS, RHS, TAIL, ENTRY)                                                                             \
+    {                                                                                                                   \
+        const bool pass_ = (LHS) <= (RHS);                                                                              \
+        const uint64_t m_ = __builtin_amdgcn_ballot_w64(pass_);                                                         \
+        if (pass_) ring_t[(rl_mbcnt(m_) + (TAIL)) & 127u] = (ENTRY);                                                    \
         TAIL += (uint32_t)__popcll(m_);                                                                                 \
     }
 #endif
@@ -599,7 +645,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // sphere tails of the direct list included, reads its pairs' rays from there.
     RlCullRay cr = rl_cull_ray(o, dir, sv_cull_cmax2, idle_bit != 0u);
     float far = best.t * cr.len;
-    rl_store_cull_ray(ws, lane, cr, far);
+    rl_store_cull_ray<PF>(ws, lane, cr, far);
+    // (RL_PROGRESSIVE_FAR) this lane's own far bound for the wave-uniform loops, refreshed behind a nested round: its key may have come nearer
+#define RL_REFRESH_FAR() \
+    if (PF) far = rl_u2f(((const RlLdsU32*)keys)[2u * lane + 1u]) * cr.len;
 
     // ---- ring B round: exact sphere tail for (record position, owner) pairs ----
     auto process_spheres = [&](uint32_t count) {
@@ -717,7 +766,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         if (RL_W_M) mb = sph[first]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
         float r_far;
-        rl_fetch_cull_ray(ws, owner, r, r_far);
+        rl_fetch_cull_ray<PF>(ws, owner, r, r_far);
         if (!RL_W_M) mb = sph[first];
         // The members that pass are collected as one bit per member in a lane-private mask (one v_alignbit per member: shift
         // left, take in the sign of the test's margin) and pushed afterwards, lowest set bit of every lane per step -- ~0.5 members pass
@@ -729,8 +778,14 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #define RL_MEMBERS(N)                                                                                                    \
         {                                                                                                                \
             uint32_t failed = 0; /* one bit per member: the sign of the test's margin, shifted in with one v_alignbit */  \
+            /* (spheres in global memory: TWO records of prefetch -- a member is a per-lane 16-byte gather from L2 / HBM, the loop is    \
+               bound by that latency, and 57 % of the time of a 5,000-sphere scene went into these rounds with one) */          \
+            RlF4 mb_ahead = RlF4();                                                                                      \
+            if (!SPHERES_IN_LDS && RL_MEMBER_AHEAD2) mb_ahead = sph[first + 1];                                           \
             for (uint32_t j = 0; j < (N); ++j) {                                                                         \
-                const RlF4 mb_next = sph[first + j + 1]; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
+                RlF4 mb_next; /* one record of prefetch (behind the last member: the next cluster's bound, or the blob's next array) */ \
+                if (!SPHERES_IN_LDS && RL_MEMBER_AHEAD2) mb_next = mb_ahead, mb_ahead = sph[first + j + 2];               \
+                else mb_next = sph[first + j + 1];                                                                       \
                 if (RL_MEMBER_FENCE) asm volatile("" ::: "memory"); /* ONE record in flight: without it a tight register budget makes the scheduler request all N up front and spill them */ \
                 failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(r, mb, r_far)), 31u); /* member j ends up at bit N - 1 - j */ \
                 mb = mb_next;                                                                                            \
@@ -822,11 +877,25 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             bnd_[0] = cull[first]; bnd_[1] = cull[first + 1u]; bnd_[2] = cull[first + 2u];              \
             if ((G) == 4u) bnd_[3] = cull[first + 3u];                                                  \
         }                                                                                               \
+        /* (the table in global memory: the rolled loop below keeps two bounds requested ahead -- a child's bound is a per-lane    \
+           gather from L2 / HBM -- the first two ahead of the cross-lane fetch) */                       \
+        constexpr bool S_AHEAD = !UNROLL_S && !TABLES_IN_LDS && SPLIT && RL_S_AHEAD2; /* (plain launches: the open ones have no registers for it) */ \
+        constexpr bool S_AHEAD_TWO = S_AHEAD;                                                           \
+        RlF4 pa_ = RlF4(), pb_ = RlF4();                                                                \
+        if (S_AHEAD) pa_ = cull[first];                                                                 \
+        if (S_AHEAD_TWO) pb_ = cull[first + 1u];                                                        \
         RlCullRay r;                                                                                    \
         float r_far;                                                                                    \
-        rl_fetch_cull_ray(ws, owner, r, r_far);                                                    \
+        rl_fetch_cull_ray<PF>(ws, owner, r, r_far);                                                    \
         if (lane >= (COUNT)) r.q = -__builtin_inff(); /* lanes beyond the round never pass */           \
-        if (UNROLL_S) {                                                                                 \
+        if (S_AHEAD) {                                                                                  \
+            _Pragma("nounroll") for (uint32_t j = 0; j < (G); ++j) {                                    \
+                const RlF4 cur_ = pa_;                                                                  \
+                if (S_AHEAD_TWO) pa_ = pb_, pb_ = cull[first + j + 2u]; /* (behind the last child: the next group's, the group bounds or the table's slack) */ \
+                else pa_ = cull[first + j + 1u];                                                        \
+                RL_GROUP_CHILD_OF(cur_, j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)                         \
+            }                                                                                           \
+        } else if (UNROLL_S) {                                                                          \
             _Pragma("unroll") for (uint32_t j = 0; j < 4u; ++j) {                                       \
                 if (j >= 3u && j >= (G)) break; /* groups hold 3 or 4 bounds (rl_scene.cpp) */          \
                 if (HOIST_S) RL_GROUP_CHILD_OF(bnd_[j], j, COUNT, G, ITEM_BASE, PROCESS_A, CYL)          \
@@ -849,6 +918,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         for (uint32_t c0 = 0; c0 < (N_GROUPS); c0 += 31u) {                                             \
             const uint32_t n_here = (N_GROUPS) - c0 < 31u ? (N_GROUPS) - c0 : 31u;                      \
             const RlF4* gb = cull + n_level1 + (FIRST_GROUP) + c0;                                      \
+            if (c0 != 0u) RL_REFRESH_FAR()                                                              \
             uint32_t failed = 0;                                                                        \
             _Pragma("unroll 4") for (uint32_t k = 0; k < n_here; ++k)                                   \
                 failed = __builtin_amdgcn_alignbit(failed, rl_f2u(rl_cull_margin(cr, gb[k], far)), 31u); /* group k at bit n_here - 1 - k */ \
@@ -890,7 +960,77 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             if (RL_UNLIKELY(s_tail >= s_lim)) {                                                         \
                 RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                       \
                 s_lim += 64u;                                                                           \
+                RL_REFRESH_FAR()                                                                        \
             }                                                                                           \
+        }                                                                                               \
+        if (s_tail != s_lim - 64u) {                                                                    \
+            const uint32_t left = s_tail - (s_lim - 64u);                                               \
+            RL_GROUP_ROUND(left, G, ITEM_BASE, PROCESS_A, CYL)                                          \
+            s_lim = s_tail + 64u;                                                                       \
+        }                                                                                               \
+    }
+    // ---- level 3 (SUPER; round 6): the cluster groups of a scene with thousands of spheres.  Every ray is tested against the SUPER
+    // bounds (one per super_g consecutive groups, behind the group bounds in the table) with wave-uniform records; the
+    // (super, ray) pairs that pass are compacted into ring T, and a ring-T round tests the super's group bounds, one pair per
+    // lane, pushing the groups that pass to ring S -- from where everything goes on as above.  A round's lane state (the
+    // owner's cull terms, the running addresses) is re-derived from the ring entry after every nested ring-S round instead
+    // of being held across it: the nesting T -> S -> A -> B is one level deeper than the registers were budgeted for.
+    // One copy of the round (the loop is written so that the full rounds and the final partial one share it), and inside it
+    // one copy of the ring-S round.
+#define RL_SUPER_ROUND(COUNT, G, ITEM_BASE, PROCESS_A, CYL)                                             \
+    {                                                                                                   \
+        rl_wave_sync();                                                                                 \
+        for (uint32_t j_ = 0;;) { /* j_: children done (wave-uniform) */                                \
+            const uint32_t te = ring_t[(rt_lim - 64u + lane) & 127u];                                    \
+            const uint32_t towner = te & 63u;                                                           \
+            const uint32_t tgroup = __umul24(super_g, lane < (COUNT) ? (te >> 6) : 0u) + j_; /* stale entries: super 0 */ \
+            const RlF4* tp = cull + n_level1 + tgroup;                                                  \
+            RlF4 tb = tp[0]; /* ahead of the cross-lane fetch: one wait for both */                     \
+            RlCullRay tr;                                                                               \
+            float tr_far;                                                                               \
+            rl_fetch_cull_ray<PF>(ws, towner, tr, tr_far);                                                  \
+            if (lane >= (COUNT)) tr.q = -__builtin_inff(); /* lanes beyond the round never pass */      \
+            uint32_t s_entry = (tgroup << 6) | towner;                                                  \
+            bool s_full = false;                                                                        \
+            while (j_ < super_g) {                                                                      \
+                const float lhs = rl_cull_lhs_apart(tr, tb, tr_far);                                    \
+                tb = *++tp; /* (behind the last group: the prism groups, the supers or the table's slack) */ \
+                RL_LE_PUSH(ring_s, lhs, tr.q, s_tail, s_entry)                                          \
+                s_entry += 64u;                                                                         \
+                j_ += 1u;                                                                               \
+                if (RL_UNLIKELY(s_tail >= s_lim)) {                                                     \
+                    s_full = true;                                                                      \
+                    break;                                                                              \
+                }                                                                                       \
+            }                                                                                           \
+            if (!s_full) break;                                                                         \
+            RL_GROUP_ROUND(64u, G, ITEM_BASE, PROCESS_A, CYL)                                           \
+            s_lim += 64u;                                                                               \
+            if (j_ >= super_g) break;                                                                   \
+        }                                                                                               \
+        rl_wave_sync();                                                                                 \
+    }
+#define RL_SUPER_CULLS(N_SUPERS, G, ITEM_BASE, PROCESS_A, CYL)                                          \
+    {                                                                                                   \
+        /* (one scalar -- the next super's number -- lives across a round; addresses, the prefetched bound and the running ring entry  \
+           are derived from it again behind each) */                                                    \
+        for (uint32_t s_next = 0;;) {                                                                   \
+            const RlF4* sb = cull + (n_level1 + n_cluster_groups + n_prism_groups + s_next);            \
+            RlF4 g0 = *sb;                                                                              \
+            uint32_t t_entry = (s_next << 6) | lane;                                                    \
+            while (s_next != (N_SUPERS) && rt_tail < rt_lim) {                                            \
+                const float lhs = rl_cull_lhs_apart(cr, g0, far);                                       \
+                g0 = *++sb; /* (behind the last super: the table's slack) */                            \
+                RL_LE_PUSH_T(lhs, cr.q, rt_tail, t_entry)                                                \
+                t_entry += 64u;                                                                         \
+                s_next += 1u;                                                                           \
+            }                                                                                           \
+            const uint32_t waiting = rt_tail - (rt_lim - 64u);                                            \
+            if (waiting == 0u) break; /* (only once the supers are exhausted) */                        \
+            const uint32_t count = waiting < 64u ? waiting : 64u;                                       \
+            RL_SUPER_ROUND(count, G, ITEM_BASE, PROCESS_A, CYL)                                         \
+            rt_lim += count;                                                                             \
+            RL_REFRESH_FAR()                                                                            \
         }                                                                                               \
         if (s_tail != s_lim - 64u) {                                                                    \
             const uint32_t left = s_tail - (s_lim - 64u);                                               \
@@ -900,7 +1040,12 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     }
     // ---- sphere clusters: group culls -> ring S -> cluster bounds -> ring A -> members -> ring B ----
     if (n_cluster_groups != 0) {
-        RL_GROUP_CULLS(0u, n_cluster_groups, group_gc, 0u, process_clusters, false)
+        if (SUPER) asm volatile("" : "+s"(n_cluster_supers), "+s"(super_g)); // (opaque here, where they are used: see the counts above)
+        if (SUPER && n_cluster_supers != 0u) {
+            RL_SUPER_CULLS(n_cluster_supers, group_gc, 0u, process_clusters, false)
+        } else {
+            RL_GROUP_CULLS(0u, n_cluster_groups, group_gc, 0u, process_clusters, false)
+        }
         RL_STAT(RL_ST_S_ITEMS, s_tail);
         if (a_tail != a_lim - 64u) process_clusters(a_tail - (a_lim - 64u));
         a_lim = a_tail + 64u;
@@ -911,13 +1056,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
 #endif
 #undef RL_SPHERE_REJECT
     RL_T1(RL_ST_T_CLUSTER, t_cluster);
-    RL_T0(t_tail);
+    RL_T0(t_tailflush);
     if (b_tail != b_lim - 64u) process_spheres(b_tail - (b_lim - 64u));
     b_lim = b_tail + 64u;
-    RL_T1(RL_ST_T_TAIL, t_tail);
+    RL_T1(RL_ST_T_TAIL, t_tailflush);
     RL_T0(t_prism);
     far = rl_u2f((uint32_t)(keys[lane] >> 32)) * cr.len; // every sphere has been merged by now (process_spheres ends in a wave sync)
-    ((RlLdsF*)&ws->far[0])[lane] = far;
+    if (!PF) ((RlLdsF*)&ws->far[0])[lane] = far;
 
     // ---- hexagonal prisms: cull -> compact -> evaluate -> merge ----
     auto process_prisms = [&](uint32_t count) {
@@ -951,7 +1096,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             {
                 asm volatile("" ::: "memory");
                 const float keep_len = cr.len;
-                rl_fetch_cull_ray(ws, lane, cr, far);
+                rl_fetch_cull_ray<PF>(ws, lane, cr, far);
                 cr.len = keep_len;
             }
             // (... and so is the pair's ring entry)
@@ -981,7 +1126,7 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
         const RlF4 cy0 = cy[0], cy1 = cy[1]; // (ahead of the cross-lane fetch: one wait for both)
         RlCullRay r;
         float r_far_unused;
-        rl_fetch_cull_ray(ws, owner, r, r_far_unused);
+        rl_fetch_cull_ray<PF>(ws, owner, r, r_far_unused);
         const bool pass = lane < count && rl_cyl_pass(r, cy0, rl_xyz(cy1));
         const uint64_t m = __builtin_amdgcn_ballot_w64(pass);
         if (m != 0) {
@@ -997,6 +1142,10 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     if (n_prism_groups != 0) {
         RL_GROUP_CULLS_MASK(n_cluster_groups, n_prism_groups, RL_GROUP_GP, group_gc * n_cluster_groups, process_prisms, CYL)
     }
+#undef RL_REFRESH_FAR
+#undef RL_SUPER_CULLS
+#undef RL_SUPER_ROUND
+#undef RL_LE_PUSH_T
 #undef RL_GROUP_CULLS
 #undef RL_GROUP_CULLS_MASK
 #undef RL_GROUP_ROUND
@@ -1064,6 +1213,13 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         __syncthreads();
         base = smem;
         scratch = (RlWaveScratch*)(smem + ((n_staged + 31u) & ~31u));
+    }
+    // A scene whose cull table has a third level (never one that is staged whole) gets 512 bytes per wave in front of the scratch
+    // blocks: ring T (rl_scan_wave, SUPER).  The host sizes the launch's LDS accordingly (rl_api.hip: ring_t_bytes).
+    RlLdsU32* ring_t = nullptr;
+    if (STAGE != RL_STAGE_ALL && lay.n_cluster_supers != 0u) {
+        ring_t = (RlLdsU32*)scratch + 128u * (threadIdx.x >> 6);
+        scratch = (RlWaveScratch*)((RlF4*)scratch + 32u * (RL_TRACE_BLOCK / 64));
     }
     const uint32_t tab0 = STAGE == RL_STAGE_TABLES ? lay.off_planes : 0u; // blob offset of `base`'s first record
 
@@ -1600,8 +1756,8 @@ __device__ __forceinline__ void rl_trace_body(const RlF4* __restrict__ scene, co
         // (round 6: the Compound tree's lean form freed ~15 registers, and the open launches of a scene that is staged whole now take
         // every one of these options inside their 120 registers; the tables-only and global-fetch open variants still do not)
         constexpr bool FULL = !OPEN || (RL_OPEN_FULL && STAGE == RL_STAGE_ALL && (FUSED || !CYL)); // (the un-fused open variant of a scene with prism cylinders spills one scalar register with them)
-        const RlHit hit = rl_scan_wave<CYL, FULL && RL_LEAN_SPLIT, STAGE != RL_STAGE_NONE && (!(FUSED && OPEN) || FULL), STAGE != RL_STAGE_NONE && (!(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) || FULL) && RL_W_S && RL_LEAN_HOIST, STAGE == RL_STAGE_ALL, STAGE != RL_STAGE_NONE>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups, p.origin,
-                                       p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
+        const RlHit hit = rl_scan_wave<CYL, FULL && RL_LEAN_SPLIT, STAGE != RL_STAGE_NONE && (!(FUSED && OPEN) || FULL), STAGE != RL_STAGE_NONE && (!(OPEN && (FUSED || STAGE == RL_STAGE_TABLES)) || FULL) && RL_W_S && RL_LEAN_HOIST, STAGE == RL_STAGE_ALL, STAGE != RL_STAGE_NONE, STAGE != RL_STAGE_ALL>(sv, base + (lay.off_cull - tab0), CYL ? base + (lay.off_prism_cyl - tab0) : nullptr, lay.group_gc, lay.small_ordered, lay.cull_cmax2, lay.n_cluster_groups, lay.n_prism_groups,
+                                       lay.n_cluster_supers, lay.super_g, ring_t, p.origin, p.direction, active ? 0u : 0x80000000u, ws, lane RL_TACC_ARG);
 #ifdef RL_STATS
         {
             const uint32_t mk = (active && hit.obj != RL_HIT_NONE) ? rl_object_material(rl_f2u(sv.objects[hit.obj].w)) : 99u;

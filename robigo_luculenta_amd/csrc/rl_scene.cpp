@@ -653,6 +653,13 @@ std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vect
 // groups and more, tighter ones.  So rl_flatten_scene builds the table for every size in RL_CLUSTER_K_CHOICES x {3, 4}
 // clusters per group and keeps the one that costs the kernel least, estimated from the rays of a few hundred sample paths
 // with the kernel's measured cost per step (plan_cost).  Which table is chosen never changes a result.
+#ifndef RL_SUPER_MIN_GROUPS
+#define RL_SUPER_MIN_GROUPS 112 // cluster groups from which the cull table gets its third level (tools/spill_ab.py with RL_SUPER_MIN / RL_SUPER_G:
+                                // 88 groups lose 3 % with it, 128-136 gain 0-10 %, 504 gain 76 %; 8 per super is at or near the best of 4 / 8 / 12 / 16 everywhere)
+#endif
+#ifndef RL_SUPER_G_DEFAULT
+#define RL_SUPER_G_DEFAULT 8   // cluster groups per super
+#endif
 struct ClusterPlan {
     uint32_t k, group_gc;
     std::vector<std::vector<uint32_t>> clusters; // in table order, short groups filled with empty clusters
@@ -964,6 +971,31 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     }
     fs.cluster_k = plan.k;
     fs.group_gc = plan.group_gc;
+    // Third level: with many cluster groups (a scene of thousands of spheres: every ray tests every group bound, 28 instructions each)
+    // the groups are ordered so that super_g consecutive ones are spatial neighbours -- the same partition scheme one level up --
+    // and get a bound of their own.  From RL_SUPER_MIN_GROUPS on (measured): such a scene is far too large to be staged whole in LDS, and
+    // only the instantiations that stage the tables or nothing carry the third level's code.  (RL_SUPER_MIN / RL_SUPER_G:
+    // measurement runs.)  Which table is chosen never changes a result.
+    {
+        uint32_t min_groups = RL_SUPER_MIN_GROUPS, sg = RL_SUPER_G_DEFAULT;
+        if (const char* e = std::getenv("RL_SUPER_MIN")) min_groups = (uint32_t)std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("RL_SUPER_G")) sg = (uint32_t)std::min(64, std::max(2, std::atoi(e)));
+        const size_t n_groups = plan.clusters.size() / plan.group_gc;
+        if (n_groups >= min_groups && n_groups > sg) {
+            std::vector<std::vector<uint32_t>> supers;
+            order_by_groups(plan.group_bounds, &supers, sg);
+            std::vector<std::vector<uint32_t>> ordered;
+            for (const std::vector<uint32_t>& members : supers) {
+                for (uint32_t g : members)
+                    for (uint32_t c = 0; c < plan.group_gc; ++c) ordered.push_back(plan.clusters[(size_t)plan.group_gc * g + c]);
+                for (size_t pad = members.size(); pad < sg; ++pad)
+                    for (uint32_t c = 0; c < plan.group_gc; ++c) ordered.push_back(std::vector<uint32_t>()); // a dummy group of dummy clusters
+            }
+            plan.clusters = ordered;
+            fs.n_cluster_supers = (uint32_t)supers.size();
+            fs.super_g = sg;
+        }
+    }
     const RlF4 never = dummy; // as a bound {c, R^2 = -inf}: fails every cull test, host and device
     std::vector<std::vector<uint32_t>>& clusters = plan.clusters;
     for (std::vector<uint32_t>& members : clusters) {
@@ -1031,13 +1063,21 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     for (uint32_t i = 0; i < n_prisms; ++i) level1.push_back(fs.prisms[RL_PRISM_STRIDE * i + 16]);
     for (const RlF4& b : level1) add_bound(b);
     const size_t n_cluster_level1 = (size_t)fs.group_gc * fs.n_cluster_groups;
+    std::vector<RlF4> level2; // the group bounds as {centre, radius^2}
     for (size_t first = 0; first < level1.size();) {
         const size_t G = first < n_cluster_level1 ? fs.group_gc : RL_GROUP_GP;
         std::vector<uint32_t> members;
         for (size_t j = first; j < first + G; ++j)
             if (!(level1[j].w == never.w)) members.push_back((uint32_t)j);
-        add_bound(members.empty() ? never : group_bound(level1, members));
+        level2.push_back(members.empty() ? never : group_bound(level1, members));
+        add_bound(level2.back());
         first += G;
+    }
+    for (uint32_t s = 0; s < fs.n_cluster_supers; ++s) { // third level: one bound per super_g cluster groups
+        std::vector<uint32_t> members;
+        for (uint32_t g = fs.super_g * s; g < fs.super_g * (s + 1u); ++g)
+            if (!(level2[g].w == never.w)) members.push_back(g);
+        add_bound(members.empty() ? never : group_bound(level2, members));
     }
     fs.cull_bounds.push_back(dummy); // slack for the kernel's prefetch
     fs.cull_bounds.push_back(dummy);

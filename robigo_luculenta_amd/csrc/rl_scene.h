@@ -97,6 +97,12 @@ struct RlFlatScene {
     std::vector<RlF4> cull_bounds;
     uint32_t n_cluster_groups, n_prism_groups; // cull_bounds = [group_gc * n_cluster_groups][GP * n_prism_groups][groups][groups][slack]
     uint32_t group_gc = 3;                     // clusters per group (3 or 4), chosen with cluster_k: rl_scene.cpp, plan_cost
+    // Third level (round 6), for scenes with many sphere clusters: one SUPER bound per super_g consecutive cluster groups, behind the
+    // group bounds in cull_bounds: [level 1][cluster groups][prism groups][cluster supers][slack].  A ray then tests the super bounds
+    // with wave-uniform records instead of every group bound; the (super, ray) pairs that pass are compacted and a round tests the
+    // super's groups, one pair per lane (rl_kernels.hip.h: ring T).  0 supers: the table has two levels, as every scene small enough
+    // to be staged whole in LDS has.  The cluster groups are padded with never-reached dummies to a multiple of super_g.
+    uint32_t n_cluster_supers = 0, super_g = 0;
     std::vector<RlF4> prism_cyl;               // 2 records per prism {point on the axis, radius}, {unit axis, 0}; empty unless
     bool prism_cylinders = false;              // ... the scene has enough prisms for the second bound to pay (rl_scene.cpp)
     std::vector<float> sphere_cull_w;          // per record of `spheres`: |c|^2 - R^2 of a clustered sphere (else +inf), see rl_flatten_scene

@@ -7,7 +7,8 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SO = os.path.join(ROOT, "oracle", "_build", "librl_oracle.so")
+SO = os.environ.get("RL_ORACLE_SO") or os.path.join(ROOT, "oracle", "_build", "librl_oracle.so")  # (RL_ORACLE_SO: the clang++ build, test_golden.py)
+SO_CLANG = os.path.join(ROOT, "oracle", "_build", "librl_oracle_clang.so")
 
 
 class RlVector3(C.Structure):

@@ -163,6 +163,21 @@ extern "C" uint32_t mirror_group_bounds(void* scene, float* out4, uint32_t cap, 
     return n_groups;
 }
 
+// The third level (round 6): one bound {centre, radius^2} per RlFlatScene::super_g consecutive cluster groups, behind the group
+// bounds in the table.  Returns the number of supers (0: a two-level table); *super_g_out = groups per super.
+extern "C" uint32_t mirror_super_bounds(void* scene, float* out4, uint32_t cap, uint32_t* super_g_out) {
+    const RlFlatScene& fs = ((MirrorScene*)scene)->flat;
+    const uint32_t first = fs.group_gc * fs.n_cluster_groups + RL_GROUP_GP * fs.n_prism_groups + fs.n_cluster_groups + fs.n_prism_groups;
+    if (super_g_out) *super_g_out = fs.super_g;
+    for (uint32_t s = 0; s < fs.n_cluster_supers && s < cap; ++s) {
+        const RlF4 r = fs.cull_bounds[first + s];
+        const double c2 = (double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z;
+        out4[4 * s] = r.x; out4[4 * s + 1] = r.y; out4[4 * s + 2] = r.z;
+        out4[4 * s + 3] = (float)(c2 - (double)r.w);
+    }
+    return fs.n_cluster_supers;
+}
+
 // ---- rl_hex_prism_fast against the tree it replaces -----------------------------------------------------------------
 // Random and adversarial (prism, ray) pairs over the prisms of `scene`: rays from anywhere, rays that start on a face
 // (as after a refraction: origin = surface point + direction * 1e-5), rays aimed at edges and vertices, rays nearly

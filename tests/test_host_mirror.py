@@ -163,6 +163,51 @@ def test_cull_table_is_conservative_by_construction():
     assert all(gc in (3, 4) and gp == 3 for gc, gp in group_sizes)
 
 
+def test_third_level_of_the_cull_table_is_conservative_and_only_for_large_scenes():
+    """Round 6: a scene with 112 or more cluster groups (several thousand spheres) gets a third level -- one SUPER bound per 8
+    consecutive cluster groups, the groups padded with never-reached dummies to a multiple of 8 -- and every real group bound lies
+    inside its super's; smaller scenes (everything that can be staged whole in LDS) keep the two-level table."""
+    import ctypes as C
+    from _random_scene import random_scene
+    L = M.lib()
+    L.mirror_group_bounds.restype = C.c_uint32
+    L.mirror_group_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mirror_super_bounds.restype = C.c_uint32
+    L.mirror_super_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    small = [M.builtin_desc(0, 0), M.builtin_desc(1, 0), M.builtin_desc(0, 158), random_scene(3, n_spheres=400, n_prisms=5)]
+    small.append(M.builtin_desc(0, 1500))   # 88 groups: measured slower with a third level
+    large = [M.builtin_desc(0, 2500), random_scene(31, n_spheres=5000, n_prisms=12, n_planes=2, n_circles=3, n_parabs=1)]
+    checked = 0
+    for which, (objs, cam) in enumerate(small + large):
+        sc = M.Scene(objs, cam)
+        g = np.zeros((4096, 4), np.float32)
+        sizes = (C.c_uint32 * 3)()
+        ng = L.mirror_group_bounds(sc.h, O.ptr(g), len(g), sizes)
+        ncg = sizes[2]
+        g = g[:ncg].astype(np.float64)
+        sup = np.zeros((1024, 4), np.float32)
+        sg = C.c_uint32(0)
+        ns = L.mirror_super_bounds(sc.h, O.ptr(sup), len(sup), C.byref(sg))
+        if which < len(small):
+            assert ns == 0
+            continue
+        assert ns >= 14 and sg.value == 8 and ncg == ns * sg.value
+        sup = sup[:ns].astype(np.float64)
+        for s in range(ns):
+            members = g[sg.value * s: sg.value * (s + 1)]
+            real = members[np.isfinite(members[:, 3]) & (members[:, 3] > 0)]
+            assert len(real) >= 1                                  # a super is never all padding
+            reach = np.sqrt(((real[:, :3] - sup[s, :3]) ** 2).sum(1)) + np.sqrt(real[:, 3])
+            assert (reach <= np.sqrt(sup[s, 3]) * (1 + 1e-6)).all(), (s, reach, sup[s])
+            checked += len(real)
+        # (and the host mirror, which scans the flattened scene's spheres linearly, still renders the oracle's photons)
+        want, segs = O.Scene(objs, cam).render(160, 90, 7, 1, 0, 1 << 9)
+        got = M.Scene(objs, cam).render(160, 90, 7, 1, 0, 1 << 9)
+        got = got[0] if isinstance(got, tuple) else got
+        assert got.tobytes() == want.tobytes()
+    assert checked >= 112 + 112
+
+
 def test_the_cull_table_is_planned_per_scene():
     """rl_flatten_scene builds the table for each cluster size the kernel has an unrolled member loop for x 3 / 4 clusters per
     group and keeps the plan its cost estimate likes best (rl_scene.cpp: plan_cost over the rays of sample paths).  The

@@ -65,7 +65,9 @@ def test_every_trace_kernel_variant_leaves_registers_for_the_small_kernels(usage
     for name, u in trace.items():
         assert u["ScratchSize"] == 0 and u.get("VGPRs Spill", 0) == 0, (name, u)
         stage = int(re.search(TRACE_NAME, name).group(1))   # RL_STAGE_NONE / TABLES / ALL
-        assert u["SGPRs Spill"] == 0 if stage == 2 else u["SGPRs Spill"] <= 24, (name, u)
+        # (round 6: the variants that do not stage the whole scene also carry the cull table's third level -- ring T, one more level of
+        # nested rounds, seven more wave-uniform values alive across them -- and spill up to 31 scalar registers to lanes of a vector register)
+        assert u["SGPRs Spill"] == 0 if stage == 2 else u["SGPRs Spill"] <= 32, (name, u)
     # ... and hence no v_readlane / v_writelane traffic from spills in the LDS variants (what is left reads a wave-uniform
     # value out of a vector register on purpose: v_readfirstlane and a handful of v_readlane of the stash hand-out)
     text = usage["__asm__"]

@@ -19,10 +19,18 @@ NAMES = ["iter", "scan_lanes", "a_rounds", "a_lanes", "b_rounds", "b_lanes", "p_
          "t_total", "t_refill", "t_small", "t_direct", "t_cluster", "t_tail", "t_prism", "t_shade", "t_emit", "t_a_rounds",
          "t_b_rounds", "t_p_rounds", "t_camera", "t_s_rounds"]
 
+def _random(seed, n):  # the scenes of tools/spill_ab.py
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _random_scene as RS
+    return RS.random_scene(seed, n_spheres=n, n_prisms=12, n_planes=2, n_circles=3, n_parabs=1)
+
+
 batches = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 which = sys.argv[2] if len(sys.argv) > 2 else "demo"
 objs, cam = {"demo": lambda: R.builtin_scene_desc(R.SCENE_DEMO), "glass": lambda: R.builtin_scene_desc(R.SCENE_GLASS_STRESS),
-             "replicated": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 158), "spill": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 1500)}[which]()
+             "replicated": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 158), "spill": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 1500),
+             "spill2500": lambda: R.builtin_scene_desc(R.SCENE_DEMO, 2500),
+             "random5k": lambda: _random(31, 5000), "random8k": lambda: _random(34, 8000), "random20k": lambda: _random(35, 20000)}[which]()
 scene = R.Scene(objs, cam)
 t, plot = R.TraceUnit(0, 1920, 1080, n_photons=64), R.PlotUnit(0, 1920, 1080)
 read = _lib.lib.rl_stats_read

@@ -42,5 +42,5 @@ print("Grays/s, fused launches of 16 batches at %dx%d: default (what it staged) 
 for name, (objs, cam) in scenes:
     scene = R.Scene(objs, cam)
     a, where = rate(scene, R.FETCH_LDS)
-    b, _ = rate(scene, R.FETCH_GLOBAL)
+    b = float("nan") if os.environ.get("SPILL_QUICK") else rate(scene, R.FETCH_GLOBAL)[0]   # (SPILL_QUICK=1: the default column only)
     print("%-36s %6d objects  %6.2f (%s) / %6.2f" % (name, len(objs), a, where, b), flush=True)
