@@ -13,27 +13,19 @@ bash tools/profile_round.sh $TAG > gpurun_out/${TAG}_console.txt 2>&1
 (timeout 300 python tools/image_parity.py 1280 720 32 demo; timeout 300 python tools/image_parity.py 1920 1080 16 demo
  timeout 300 python tools/image_parity.py 1280 720 16 glass) > $OUT/image_parity.txt 2>&1
 for s in demo glass replicated spill; do timeout 120 python tools/kernel_stats.py 64 $s; done > $OUT/kernel_stats.txt 2>&1
+for s in spill2500 random5k random20k; do timeout 200 python tools/kernel_stats.py 8 $s; done >> $OUT/kernel_stats.txt 2>&1
 (timeout 1200 python tools/big_parity.py 256 demo; timeout 500 python tools/big_parity.py 96 glass
  timeout 500 python tools/big_parity.py 128 replicated; timeout 900 python tools/random_scene_sweep.py 1000
  timeout 900 python tools/random_scene_sweep.py 100 32768 big) > $OUT/big_parity.txt 2>&1
-python - > $OUT/app.txt <<'PY'
+(timeout 900 python tools/app_table.py; echo; echo "What the DEVICE does without the worker pool (tools/unfused_ceiling.py):"; timeout 200 python tools/unfused_ceiling.py
+ python - <<'PY'
 import robigo_luculenta_amd as R
-print("rl_app_run, built-in scene, 1280x720, 4096 batches of 524288 paths (trace_unit.rs:67), seconds include the final tonemap")
-for blocking in (False, True):
-    print("tasks begin their render, the next task that uses it ends it (default):" if not blocking else
-          "tasks wait for their own paths like a reference worker (blocking_trace):")
-    for fused in (False, True):
-        for c in (1, 2, 4, 8, 16):
-            rgb, st = R.app_run(1280, 720, 4096, concurrency=c, photons_per_batch=524288, fused=fused, blocking_trace=blocking, verbose=False)
-            print(" ", "fused" if fused else "un-fused", "workers", c, round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6),
-                  "Mrays/s", round(st["paths"] / 524288 / st["seconds"]), "batches/s", st["tasks"], flush=True)
-print("open launches so far, {calls carried: launches}:", R.batch_histogram())
-for fused in (False, True):
-    rgb, st = R.app_run(1280, 720, 96, concurrency=2, photons_per_batch=64 * 524288, fused=fused, verbose=False)
-    print("fused" if fused else "un-fused", "64-batch tasks, workers 2", round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s")
 rgb, st = R.app_run(1280, 720, 1024, concurrency=4, photons_per_batch=524288, fused=True, devices=[0, 0], verbose=False)
-print("fused, two ranks on one GPU (devices = [0, 0]), workers 4", round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s", st["paths"], "paths")
+print("fused, two ranks on one GPU (devices = [0, 0]), depth 4", round(st["seconds"], 3), "s", round(st["segments"] / st["seconds"] / 1e6), "Mrays/s", st["paths"], "paths")
 PY
+) > $OUT/app.txt 2>&1
+# scenes beyond LDS: the default, without the third table level, and what each staged
+(export SPILL_QUICK=1; echo "== default"; timeout 400 python tools/spill_ab.py 2>&1 | grep -E "objects|Grays"; echo "== RL_SUPER_MIN=99999 (two-level table)"; RL_SUPER_MIN=99999 timeout 400 python tools/spill_ab.py 2>&1 | grep objects) > $OUT/spill_ab.txt 2>&1
 (echo '$ python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64   # two ranks share GPU 0'
  timeout 600 python bench.py --gpus 2 --dist-backend gloo --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64) > $OUT/bench_2ranks_gloo.txt 2>&1
 (echo '$ python bench.py --gpus 1 --dist-backend rccl  (one rank; for comparison)'; timeout 300 python bench.py --steps 4 --warmup 1 --launches-per-step 2 --batches-per-launch 64 --no-others --no-cpu-baseline --no-live-counters) >> $OUT/bench_2ranks_gloo.txt 2>&1
@@ -43,5 +35,5 @@ bash tools/lds_conflicts.sh $TAG > /dev/null 2>&1
 bash tools/pmc_stalls.sh $TAG demo-1080p > $OUT/instruction_mix.txt 2>&1; bash tools/pmc_stalls.sh $TAG glass-720p >> $OUT/instruction_mix.txt 2>&1
 # every kind of instruction per 64-ray segment and the split of a wave's time (round 5: what the kernel's time is made of)
 for CF in "demo-1080p lds" "glass-720p lds" "replicated-1080p lds" "replicated-1080p global"; do set -- $CF; bash tools/pmc_mix.sh $TAG $1 $2 | grep -v "^\[" ; done > $OUT/wave_time.txt 2>&1
-cat $OUT/app.txt $OUT/big_parity.txt $OUT/image_parity.txt
+cat $OUT/app.txt $OUT/spill_ab.txt $OUT/big_parity.txt $OUT/image_parity.txt
 tail -12 gpurun_out/${TAG}_console.txt | cut -c1-400

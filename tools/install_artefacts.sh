@@ -13,6 +13,7 @@ cp $SRC/${TAG}_*_pmc.json profiles/ 2>/dev/null || true   # the other BASELINE c
 cp $SRC/image_parity.txt profiles/${TAG}_image_parity.txt
 cp $SRC/kernel_stats.txt profiles/${TAG}_kernel_event_stats.txt
 cp $SRC/app.txt profiles/${TAG}_app.txt
+[ -f $SRC/spill_ab.txt ] && cp $SRC/spill_ab.txt profiles/${TAG}_spill_ab_final.txt
 cp $SRC/big_parity.txt profiles/${TAG}_big_parity.txt
 cp $SRC/bench_2ranks_gloo.txt profiles/${TAG}_bench_2ranks_gloo.txt
 cp $SRC/valu_microbench.txt profiles/${TAG}_valu_microbench.txt
