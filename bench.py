@@ -796,10 +796,10 @@ def main():
                          "traffic_note": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB of the profile named in `executed`, scaled to this run's paths per launch "
                                          "(each f32 atomic is billed as one 32-byte write); algorithmic: 48 B per contributing path; "
                                          "null when the profile is stale",
-                         "note": "no dense contraction -> no MFMA; HBM traffic is the XYZ splat only.  The kernel is bound by what a WAVE can issue at four waves "
-                                 "per SIMD: a wave's time is ~50 % issuing instructions (vector, scalar and LDS instructions cost it alike, a taken branch two), "
-                                 "~30 % waiting for LDS round trips, ~20 % issue-stalled; the vector ALU is ~68 % busy (valu_busy).  DESIGN.md 4.2, "
-                                 "profiles/r05_issue_cost_probes.txt"},
+                         "note": "no dense contraction -> no MFMA; HBM traffic is the XYZ splat only (3 % of peak).  Bound: the vector ALU's issue slots at four waves per SIMD -- "
+                                 "the kernel issues one vector instruction per ~2.75 cycles per SIMD against ~2.6 for a plain stream of independent FMAs at this "
+                                 "occupancy (issue_ceiling.kernel_vs_plain_stream), a fifth wave per SIMD gains 0.4-1.7 % (profiles/r06_fifth_wave.txt): what is left "
+                                 "is fewer vector instructions per ray.  DESIGN.md 4.1"},
         }
         if world == 1 and not args.no_others:
             out["config"]["others"] = [measure(R, c, f, rank, 6, 64, 1, args.seed, device) for c, f in OTHERS]

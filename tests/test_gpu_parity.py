@@ -582,6 +582,52 @@ def test_random_scenes_of_thousands_of_objects_spill_and_stay_bit_exact(seed):
     assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["random-6000", "built-in-2500-seeds", "random-20000"])
+def test_third_table_level_scenes_bit_exact_in_every_launch_kind(which):
+    """Round 6: scenes whose cull table has a third level (>= 112 cluster groups: SUPER bounds, ring T) and whose rounds use the
+    progressive far bound -- the variants that do not stage the whole scene.  Tables staged (where they fit) and nothing staged,
+    plain and open launches, un-fused byte for byte against the oracle, fused by its segment count and its XYZ image within the
+    atomic-order tolerance; the host-side planner (same code on the box, tests/host_mirror) confirms that the scene HAS the level."""
+    import _mirror as M
+    import _random_scene as RS
+    if which == "random-6000":
+        objs, cam = RS.random_scene(41, n_spheres=6000, n_prisms=12, n_planes=2, n_circles=3, n_parabs=1)
+    elif which == "random-20000":
+        objs, cam = RS.random_scene(35, n_spheres=20000, n_prisms=12, n_planes=2, n_circles=3, n_parabs=1)
+    else:
+        objs, cam = R.builtin_scene_desc(R.SCENE_DEMO, 2500)
+    L = M.lib()
+    L.mirror_super_bounds.restype = C.c_uint32
+    L.mirror_super_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    sup, sg = np.zeros((1024, 4), np.float32), C.c_uint32(0)
+    assert L.mirror_super_bounds(M.Scene(objs, _ocam(cam)).h, O.ptr(sup), len(sup), C.byref(sg)) >= 14 and sg.value == 8
+    scene, oscene = R.Scene(objs, cam), O.Scene(objs, _ocam(cam))
+    W, H, N = 160, 90, 1 << 12
+    want, segs = oscene.render(W, H, 9, 3, 128, N, threads=8)
+    want_xyz = O.plot(W, H, want)
+    scale = np.abs(want_xyz).max()
+    for fetch in (R.FETCH_LDS, R.FETCH_GLOBAL):
+        t = R.TraceUnit(0, W, H, n_photons=N)
+        t.set_fetch(fetch)
+        before = R.variant_launches()
+        t.render(scene, seed=9, stream=3, first_path_index=128)                       # an open launch
+        assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == segs, (which, fetch, "open")
+        t.render_async(scene, seed=9, stream=3, first_path_index=128)                 # a plain launch
+        t.sync()
+        assert t.mapped_photons.tobytes() == want.tobytes() and t.stats()[1] == 2 * segs, (which, fetch, "plain")
+        p = R.PlotUnit(0, W, H)
+        t.render_fused(scene, p, N, seed=9, stream=3, first_path_index=128)
+        t.sync()
+        assert t.stats()[1] == 3 * segs and np.allclose(p.tristimulus_buffer, want_xyz, rtol=2e-5, atol=1e-6 * scale), (which, fetch, "fused")
+        ran = [a - b for a, b in zip(R.variant_launches(), before)]
+        assert sum(ran[8:16]) == 0                                                    # never the whole-scene variants
+        if fetch == R.FETCH_GLOBAL or which == "random-20000":
+            assert sum(ran[16:]) == 0 and sum(ran[:8]) == 3                           # nothing staged
+        else:
+            assert sum(ran[16:]) == 3                                                 # the tables staged
+
+
 def test_degenerate_scenes_and_empty_launches(demo):
     """Edge cases of the scan: the empty scene (every path ends in The Void, scene.rs:43-60 returns None),
     scenes that hold a single surface kind (each of the kernel's per-kind loops runs with the others
