@@ -434,7 +434,7 @@ int rl_scene_create(const RlSceneDesc* desc, int device, RlScene** out) {
     lay.off_prism_cyl = append(fs.prism_cyl);
     lay.prism_cylinders = fs.prism_cylinders ? 1u : 0u;
     lay.group_gc = fs.group_gc;
-    lay.small_ordered = fs.small_ordered ? 1u : 0u;
+    lay.small_ordered = (fs.small_ordered ? 1u : 0u) | (fs.small_axis_z ? 2u : 0u); // (bit 1: rl_scan_wave, the six small primitives of the built-in room)
     lay.off_camera = append(fs.camera_rec);
     lay.cull_cmax2 = fs.cull_cmax2;
     // ... then the per-object arrays

@@ -257,12 +257,13 @@ RL_HD void rl_begin_path(const RlSceneView& sv, float aspect_ratio, uint64_t see
 // ---- the scan: scene.rs:39-60 over the flat records --------------------------------------------
 
 // geometry.rs:55-71 without the position.  Returns t > 0 or a negative number for "no hit".
+template <bool AXIS_Z = false> // (AXIS_Z: see rl_paraboloid_t)
 RL_HD float rl_plane_t(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* dn_out) {
     const RlF3 lo = rl_sub(o, off);
-    const float dn = rl_dot(n, dir);
+    const float dn = AXIS_Z ? n.z * dir.z : rl_dot(n, dir);
     *dn_out = dn;
     // Branch-free: for dn == 0 the quotient is inf/NaN and is discarded; `t > 0` is false for NaN.
-    const float t = -rl_dot(n, lo) / dn;
+    const float t = -(AXIS_Z ? n.z * lo.z : rl_dot(n, lo)) / dn;
     return (dn != 0.0f && t > 0.0f) ? t : -1.0f;
 }
 // geometry.rs:123-127
@@ -284,11 +285,19 @@ RL_HD float rl_paraboloid_roots(float a, float b, float c) { // geometry.rs:316-
     if (q > 0.0f) return q;
     return -1.0f;
 }
+// AXIS_Z (device, round 6): the caller knows that normal.x and normal.y are zeros -- every paraboloid, plane and circle of the built-in
+// room has its normal along z (app.rs:179-231), RlFlatScene::small_axis_z -- and the two dot products with the normal are one
+// product each.  rl_dot(normal, v) = (0 v.x + 0 v.y) + normal.z v.z IS normal.z v.z for finite v, except for the SIGN of a zero
+// result (the sum of the two zero products may be +0 where normal.z v.z is -0).  A zero n.d or n.o cannot change what is returned:
+// n.d enters squared (a) and through 2 n.d n.o - 2 d.f, whose sign matters only where it and the discriminant's root are both zero --
+// then np = -b + 0 is +0 for either sign of b, never < 0, and nq = +-0 is not < 0 either: no hit both ways; a plane with
+// n.d = +-0 is rejected by `dn != 0`, and with n.lo = +-0 its t = -+0 fails `t > 0` both ways.
+template <bool AXIS_Z = false>
 RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir) {
     const RlF3 origin = rl_sub(o, offset);
     const RlF3 focal_offset = rl_sub(origin, focal_point);
-    const float n_dot_d = rl_dot(normal, dir);
-    const float n_dot_o = rl_dot(normal, origin);
+    const float n_dot_d = AXIS_Z ? normal.z * dir.z : rl_dot(normal, dir);
+    const float n_dot_o = AXIS_Z ? normal.z * origin.z : rl_dot(normal, origin);
     const float d_dot_f = rl_dot(dir, focal_offset);
     const float a = n_dot_d * n_dot_d - 1.0f;
     const float b = 2.0f * n_dot_d * n_dot_o - 2.0f * d_dot_f;

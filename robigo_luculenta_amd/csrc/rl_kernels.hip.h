@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <type_traits>
 
 #include "rl_cie1931.h"
 #include "rl_core.h"
@@ -72,6 +73,9 @@
 #endif
 #ifndef RL_SMALL_UNROLL
 #define RL_SMALL_UNROLL 1
+#endif
+#ifndef RL_DIRECT_ONE
+#define RL_DIRECT_ONE 1
 #endif
 #ifndef RL_S_AHEAD2
 #define RL_S_AHEAD2 1 // ring-S rounds of a scene whose cull table is in global memory: two children's bounds requested ahead
@@ -546,6 +550,13 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     asm volatile("" : "+s"(n_parabs), "+s"(n_planes), "+s"(n_direct), "+s"(cluster_k), "+s"(n_cluster_groups), "+s"(n_prism_groups), "+s"(group_gc), "+s"(small_ordered));
 
     // Paraboloids, planes and circles: a handful of records, evaluated in registers.
+    // (round 6: a scene with ONE direct sphere -- the built-in scenes' sun -- has its record requested here, ahead of the small
+    // primitives' arithmetic, and tested straight-line below instead of in the direct list's loop with its four-record prefetch)
+    RlF4 first_direct = RlF4();
+    if (SPHERES_IN_LDS && RL_DIRECT_ONE) {
+        first_direct = sph[0]; // (the list is padded: record 0 always exists)
+        asm volatile("" ::: "memory");
+    }
     RlHit best;
     best.t = 1.0e12f; // scene.rs:43
     best.obj = RL_HIT_NONE;
@@ -585,50 +596,57 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // (three paraboloids and three planes / circles -- the room of every built-in scene, app.rs:166-236 -- get straight-line code: the
     // records' addresses are immediates, their loads can be requested ahead of the arithmetic that is in the way, and the two loops'
     // counters and branches go; any other count takes the loops)
-    if (RL_SMALL_UNROLL && TABLES_IN_LDS && small_ordered != 0u && n_parabs == 3u && n_planes == 3u) { // (from global memory the records are scalar loads: two objects in flight cost 24 scalar registers the global-fetch variants do not have)
+    if (RL_SMALL_UNROLL && TABLES_IN_LDS && (small_ordered & 1u) != 0u && n_parabs == 3u && n_planes == 3u) { // (from global memory the records are scalar loads: two objects in flight cost 24 scalar registers the global-fetch variants do not have)
+        // (bit 1 of the flag word: every normal of the six is along z -- the built-in room's are -- and the dot products with it are
+        // one product each, rl_paraboloid_t<AXIS_Z>: ~50 instructions of the ~390 this block costs a wave per iteration)
+        auto six = [&](auto axz) {
+            constexpr bool AXZ = decltype(axz)::value;
         // One object's records in flight behind the previous object's arithmetic: six exposed LDS round trips become one.  (The
-        // arithmetic has wave-uniform fallback branches -- short square root, one-division form -- so the scheduler, which works on
-        // basic blocks, never moves a load up by itself; the fences keep the loads where they are written.)
-        auto parab = [&](const RlF4& r0, const RlF4& r1, const RlF4& r2) {
-            if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* 16-byte LDS loads */
-            const float t = rl_paraboloid_t(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
-            const bool nearer = !(t < 0.0f) & (t < best.t);
-            best.t = nearer ? t : best.t;
-            best.obj = nearer ? rl_f2u(r0.w) : best.obj;
-        };
-        auto plane = [&](const RlF4& r0, const RlF4& r1) {
-            float dn;
-            const float t = rl_plane_t(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
-            bool hit = t > 0.0f;
-            if (hit && r0.w >= 0.0f) {
-                const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
-                hit = rl_dot(dp, dp) <= r0.w;
-            }
-            const bool nearer = hit & (t < best.t);
-            best.t = nearer ? t : best.t;
-            best.obj = nearer ? rl_f2u(r1.w) : best.obj;
-        };
+            // arithmetic has wave-uniform fallback branches -- short square root, one-division form -- so the scheduler, which works on
+            // basic blocks, never moves a load up by itself; the fences keep the loads where they are written.)
+            auto parab = [&](const RlF4& r0, const RlF4& r1, const RlF4& r2) {
+                if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* 16-byte LDS loads */
+                const float t = rl_paraboloid_t<AXZ>(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
+                const bool nearer = !(t < 0.0f) & (t < best.t);
+                best.t = nearer ? t : best.t;
+                best.obj = nearer ? rl_f2u(r0.w) : best.obj;
+            };
+            auto plane = [&](const RlF4& r0, const RlF4& r1) {
+                float dn;
+                const float t = rl_plane_t<AXZ>(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
+                bool hit = t > 0.0f;
+                if (hit && r0.w >= 0.0f) {
+                    const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
+                    hit = rl_dot(dp, dp) <= r0.w;
+                }
+                const bool nearer = hit & (t < best.t);
+                best.t = nearer ? t : best.t;
+                best.obj = nearer ? rl_f2u(r1.w) : best.obj;
+            };
 #define RL_FENCE asm volatile("" ::: "memory")
-        const RlF4 a0 = sv.parabs[0], a1 = sv.parabs[1], a2 = sv.parabs[2];
-        RL_FENCE;
-        const RlF4 b0 = sv.parabs[3], b1 = sv.parabs[4], b2 = sv.parabs[5];
-        RL_FENCE;
-        parab(a0, a1, a2);
-        const RlF4 c0 = sv.parabs[6], c1 = sv.parabs[7], c2 = sv.parabs[8];
-        RL_FENCE;
-        parab(b0, b1, b2);
-        const RlF4 d0 = sv.planes[0], d1 = sv.planes[1];
-        RL_FENCE;
-        parab(c0, c1, c2);
-        const RlF4 e0 = sv.planes[2], e1 = sv.planes[3];
-        RL_FENCE;
-        plane(d0, d1);
-        const RlF4 f0 = sv.planes[4], f1 = sv.planes[5];
-        RL_FENCE;
-        plane(e0, e1);
-        plane(f0, f1);
+            const RlF4 a0 = sv.parabs[0], a1 = sv.parabs[1], a2 = sv.parabs[2];
+            RL_FENCE;
+            const RlF4 b0 = sv.parabs[3], b1 = sv.parabs[4], b2 = sv.parabs[5];
+            RL_FENCE;
+            parab(a0, a1, a2);
+            const RlF4 c0 = sv.parabs[6], c1 = sv.parabs[7], c2 = sv.parabs[8];
+            RL_FENCE;
+            parab(b0, b1, b2);
+            const RlF4 d0 = sv.planes[0], d1 = sv.planes[1];
+            RL_FENCE;
+            parab(c0, c1, c2);
+            const RlF4 e0 = sv.planes[2], e1 = sv.planes[3];
+            RL_FENCE;
+            plane(d0, d1);
+            const RlF4 f0 = sv.planes[4], f1 = sv.planes[5];
+            RL_FENCE;
+            plane(e0, e1);
+            plane(f0, f1);
 #undef RL_FENCE
-    } else if (small_ordered != 0u) {
+        };
+        if ((small_ordered & 2u) != 0u) six(std::integral_constant<bool, true>());
+        else six(std::integral_constant<bool, false>());
+    } else if ((small_ordered & 1u) != 0u) {
         RL_SMALL_PRIMITIVES(RL_NEARER_ORDERED, n_parabs, n_planes)
     } else {
         RL_SMALL_PRIMITIVES(rl_nearer, n_parabs, n_planes)
@@ -715,7 +733,9 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
     // ---- direct spheres: every ray against every record; groups of 4 with one group of prefetch, then
     // the remainder one by one (the padding of rl_scene.h keeps every prefetch in bounds) ----
     RL_T0(t_direct);
-    if (n_direct != 0) {
+    if (SPHERES_IN_LDS && RL_DIRECT_ONE && n_direct == 1u) {
+        RL_SPHERE_REJECT(first_direct, 0u, lane, idle_bit, o.x, o.y, o.z, dir.x, dir.y, dir.z)
+    } else if (n_direct != 0) {
         const uint32_t full = n_direct & ~3u;
         RlF4 c0 = sph[0], c1 = sph[1], c2 = sph[2], c3 = sph[3];
         for (uint32_t i = 0; i < full; i += 4) { // (each record is re-loaded in place once it has been tested: no copies, see RL_GROUP_CULLS)

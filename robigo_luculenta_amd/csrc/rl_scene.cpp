@@ -1089,6 +1089,10 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
         for (size_t i = 3; i < fs.parabs.size(); i += 3) sorted = sorted && rl_f2u(fs.parabs[i - 3].w) < rl_f2u(fs.parabs[i].w);
         for (size_t i = 3; i < fs.planes.size(); i += 2) sorted = sorted && rl_f2u(fs.planes[i - 2].w) < rl_f2u(fs.planes[i].w);
         fs.small_ordered = sorted;
+        bool axis_z = !(fs.parabs.empty() && fs.planes.empty());
+        for (size_t i = 1; i < fs.parabs.size(); i += 3) axis_z = axis_z && fs.parabs[i].x == 0.0f && fs.parabs[i].y == 0.0f;
+        for (size_t i = 0; i < fs.planes.size(); i += 2) axis_z = axis_z && fs.planes[i].x == 0.0f && fs.planes[i].y == 0.0f;
+        fs.small_axis_z = axis_z;
     }
     // The clustered spheres in the cull's form: the fourth component a cluster-member record carries on the DEVICE
     // instead of radius^2 (rl_api.hip swaps it in; the exact radius^2 goes to a separate float array that only the exact

@@ -111,6 +111,9 @@ struct RlFlatScene {
     // small primitives (paraboloids, then planes) then visits objects in ascending order and `t < best.t` alone is scene.rs:51's
     // "the first object wins a tie" (RlSceneLayout::small_ordered; the built-in scenes).  Other scenes take the general compare.
     bool small_ordered = false;
+    // Every paraboloid's, plane's and circle's normal is along z (x and y components zero): the kernel's straight-line block for the
+    // built-in room then takes the dot products with a normal as one product (rl_paraboloid_t<AXIS_Z>); RlSceneLayout::small_ordered bit 1.
+    bool small_axis_z = false;
     std::vector<uint32_t> sphere_obj;
     uint32_t n_direct, n_direct_padded, cluster_base, n_clusters, cluster_k; // see RlSceneView
     RlCameraDesc camera;

@@ -109,6 +109,23 @@ def small_ordered(scene):
     return bool(L.mirror_small_ordered(scene.h))
 
 
+def small_axis_z(scene):
+    """RlFlatScene::small_axis_z of `scene`: every paraboloid's, plane's and circle's normal lies along z."""
+    L = lib()
+    L.mirror_small_axis_z.restype = C.c_int
+    L.mirror_small_axis_z.argtypes = [C.c_void_p]
+    return bool(L.mirror_small_axis_z(scene.h))
+
+
+def axis_z_check(seed, n):
+    """rl_paraboloid_t<AXIS_Z> / rl_plane_t<AXIS_Z> against the general forms: (cases, hits compared, differences, cases with a zero n.d / n.o)."""
+    L = lib()
+    L.mirror_axis_z_check.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    c = np.zeros(4, np.uint64)
+    L.mirror_axis_z_check(seed, n, O.ptr(c))
+    return tuple(int(x) for x in c)
+
+
 def cull_counts(scene, w, h, seed, stream, first, n):
     """What the kernel's sphere pass does with `scene`'s cull table on the segments of paths [first, first + n), counted on
     the host: per segment the (group, ray), (cluster, ray) and (member, ray) pairs that pass, and the table's shape."""

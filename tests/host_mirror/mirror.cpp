@@ -178,6 +178,63 @@ extern "C" uint32_t mirror_super_bounds(void* scene, float* out4, uint32_t cap, 
     return fs.n_cluster_supers;
 }
 
+// rl_paraboloid_t<AXIS_Z> / rl_plane_t<AXIS_Z> against the general forms for normals along z (round 6): random and adversarial
+// rays -- direction or origin components that are exact zeros of either sign, origins at the primitive's own height, rays along
+// the axis -- and normals (+-0, +-0, +-1).  Equivalent = the scan's use of the result is the same: both "no hit" (t < 0, NaN, or not
+// below the scan's initial 1e12) or the same float.  counts[0] = cases, [1] = hits compared bit for bit, [2] = differences (must be 0),
+// [3] = cases in which n.d or n.o is a zero (where the two forms may differ in that zero's sign).
+extern "C" void mirror_axis_z_check(uint64_t seed, uint64_t n, uint64_t* counts) {
+    for (int i = 0; i < 4; ++i) counts[i] = 0;
+    uint64_t s = seed;
+    auto next = [&]() {
+        s += 0x9e3779b97f4a7c15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto unit = [&]() { return (float)(next() >> 40) * (1.0f / 16777216.0f) * 2.0f - 1.0f; };
+    auto comp = [&](float scale) { // a component: mostly random, sometimes an exact zero of either sign or a tiny number
+        const uint64_t k = next() % 16;
+        if (k == 0) return 0.0f;
+        if (k == 1) return -0.0f;
+        if (k == 2) return 1.0e-30f * unit();
+        return scale * unit();
+    };
+    auto used = [](float t) { return !(t < 0.0f) && t < 1.0e12f; }; // what rl_scan_wave does with a paraboloid's t
+    for (uint64_t i = 0; i < n; ++i) {
+        const float nz = (next() & 1) ? 1.0f : -1.0f;
+        const RlF3 normal = rl_f3((next() & 1) ? 0.0f : -0.0f, (next() & 1) ? 0.0f : -0.0f, nz);
+        const RlF3 offset = rl_f3(comp(30.0f), comp(30.0f), comp(30.0f));
+        const RlF3 focal = rl_f3(comp(30.0f), comp(30.0f), comp(30.0f));
+        RlF3 o = rl_f3(comp(60.0f), comp(60.0f), comp(60.0f));
+        if (next() % 8 == 0) o.z = offset.z; // at the primitive's own height: n.o is a zero
+        RlF3 d = rl_f3(comp(1.0f), comp(1.0f), comp(1.0f));
+        if (next() % 16 == 0) d = rl_f3((next() & 1) ? 0.0f : -0.0f, (next() & 1) ? 0.0f : -0.0f, (next() & 1) ? 1.0f : -1.0f); // along the axis
+        counts[0] += 2;
+        const float lo_z = o.z - offset.z;
+        if (d.z == 0.0f || lo_z == 0.0f) counts[3] += 1;
+        {
+            const float a = rl_paraboloid_t<false>(offset, normal, focal, o, d), b = rl_paraboloid_t<true>(offset, normal, focal, o, d);
+            if (used(a) != used(b)) counts[2] += 1;
+            else if (used(a)) {
+                counts[1] += 1;
+                if (rl_f2u(a) != rl_f2u(b)) counts[2] += 1;
+            }
+        }
+        {
+            float dn_a, dn_b;
+            const float a = rl_plane_t<false>(normal, offset, o, d, &dn_a), b = rl_plane_t<true>(normal, offset, o, d, &dn_b);
+            const bool hit_a = a > 0.0f, hit_b = b > 0.0f; // what the plane / circle code does with it
+            if (hit_a != hit_b) counts[2] += 1;
+            else if (hit_a) {
+                counts[1] += 1;
+                if (rl_f2u(a) != rl_f2u(b)) counts[2] += 1;
+            }
+        }
+    }
+}
+
 // ---- rl_hex_prism_fast against the tree it replaces -----------------------------------------------------------------
 // Random and adversarial (prism, ray) pairs over the prisms of `scene`: rays from anywhere, rays that start on a face
 // (as after a refraction: origin = surface point + direction * 1e-5), rays aimed at edges and vertices, rays nearly
@@ -380,6 +437,8 @@ static bool mirror_reach(RlF4 b, RlF3 o, RlF3 dir, double far_t) {
 }
 // RlFlatScene::small_ordered: may the kernel decide ties among the small primitives by scan order alone?
 extern "C" int mirror_small_ordered(void* scene) { return ((MirrorScene*)scene)->flat.small_ordered ? 1 : 0; }
+// RlFlatScene::small_axis_z: every paraboloid's, plane's and circle's normal lies along z (the kernel then takes n.v as n.z v.z)
+extern "C" int mirror_small_axis_z(void* scene) { return ((MirrorScene*)scene)->flat.small_axis_z ? 1 : 0; }
 
 extern "C" void mirror_cull_counts(void* scene, uint32_t w, uint32_t h, uint64_t seed, uint32_t stream, uint64_t first, uint64_t n,
                                    uint64_t* counts) {

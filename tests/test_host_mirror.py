@@ -208,6 +208,24 @@ def test_third_level_of_the_cull_table_is_conservative_and_only_for_large_scenes
     assert checked >= 112 + 112
 
 
+def test_normals_along_z_take_one_product_and_change_no_result():
+    """Round 6: the built-in room's paraboloids, plane and circles all have normals along z (app.rs:179-231); the kernel's straight-line
+    block for them takes dot(normal, v) as normal.z * v.z (rl_paraboloid_t<AXIS_Z>, rl_plane_t<AXIS_Z>) when rl_flatten_scene says so.
+    The two forms can differ in the SIGN of a zero dot product only, and that never changes what the scan does with the result:
+    4 M adversarial cases (exact zeros of either sign in the ray, origins at the primitive's height, rays along the axis)."""
+    from _random_scene import random_scene
+    assert M.small_axis_z(M.Scene(*M.builtin_desc(0, 0))) and M.small_axis_z(M.Scene(*M.builtin_desc(1, 0))) and M.small_axis_z(M.Scene(*M.builtin_desc(0, 158)))
+    objs, cam = random_scene(5, n_spheres=30, n_prisms=2, n_planes=2, n_circles=2, n_parabs=2)
+    assert not M.small_axis_z(M.Scene(objs, cam))                       # random normals
+    objs, cam = M.builtin_desc(0, 0)
+    tilted = objs.copy()
+    k = int(np.nonzero(tilted["surface_kind"] == 1)[0][0])             # the ceiling plane, tilted by a hair
+    tilted["v0"][k] = (1.0e-3, 0.0, -1.0)
+    assert not M.small_axis_z(M.Scene(tilted, cam))
+    cases, hits, differences, zeros = M.axis_z_check(2026, 2_000_000)
+    assert cases == 4_000_000 and differences == 0 and hits > 400_000 and zeros > 300_000, (cases, hits, differences, zeros)
+
+
 def test_the_cull_table_is_planned_per_scene():
     """rl_flatten_scene builds the table for each cluster size the kernel has an unrolled member loop for x 3 / 4 clusters per
     group and keeps the plan its cost estimate likes best (rl_scene.cpp: plan_cost over the rays of sample paths).  The
