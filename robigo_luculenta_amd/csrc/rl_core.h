@@ -83,10 +83,12 @@ RL_HD RlF3 rl_normalise(RlF3 v) {                                               
     // rcp, e = fma(-m, y, 1), y = fma(e, y, y), q = x y, r = fma(-m, q, x), q = fma(r, y, q), r = fma(-m, q, x),
     // q = fma(r, y, q) -- so the quotients are the compiler's bit for bit (the parity tests compare them with the g++
     // build's divisions); a zero keeps its sign.  Any other operand in the wave: the plain forms below.
-    const uint32_t bx = rl_f2u(v.x) & 0x7fffffffu, by = rl_f2u(v.y) & 0x7fffffffu, bz = rl_f2u(v.z) & 0x7fffffffu;
-    uint32_t least = bx - 1u < by - 1u ? bx - 1u : by - 1u; // (0 - 1 wraps to the largest value: zeros pass)
-    least = bz - 1u < least ? bz - 1u : least;
-    const bool plain = (least >= 0x1f800000u - 1u)                       // every component is 0 or at least 2^-64
+    // (round 6: 2|x| - 1 instead of |x| - 1 -- the shift drops the sign, so each component costs one v_lshl_add_u32 instead of a
+    // v_and and a v_add; for 1 <= |x| bits: 2|x| - 1 >= 2K - 1 <=> |x| >= K, and a zero still wraps to the largest value)
+    const uint32_t bx = (rl_f2u(v.x) << 1) - 1u, by = (rl_f2u(v.y) << 1) - 1u, bz = (rl_f2u(v.z) << 1) - 1u;
+    uint32_t least = bx < by ? bx : by;
+    least = bz < least ? bz : least;
+    const bool plain = (least >= 2u * 0x1f800000u - 1u)                  // every component is 0 or at least 2^-64
                        & (rl_f2u(d2) - 0x0f800000u < 0x7a800000u - 0x0f800000u); // 2^-96 <= |v|^2 < 2^118: 2^-48 <= m < 2^59 (NaN and 0 fail)
     if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) {
         const float ys = __builtin_amdgcn_rsqf(d2);
@@ -266,6 +268,16 @@ RL_HD float rl_plane_t(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* dn_out) {
     const float t = -(AXIS_Z ? n.z * lo.z : rl_dot(n, lo)) / dn;
     return (dn != 0.0f && t > 0.0f) ? t : -1.0f;
 }
+// The same as a predicate (round 6, the kernel's straight-line block): "t > 0 and the ray is not parallel" without the detour through
+// a -1 that the caller compares with zero again; *t_out is the quotient whatever the answer.
+template <bool AXIS_Z = false>
+RL_HD bool rl_plane_hit(RlF3 n, RlF3 off, RlF3 o, RlF3 dir, float* t_out) {
+    const RlF3 lo = rl_sub(o, off);
+    const float dn = AXIS_Z ? n.z * dir.z : rl_dot(n, dir);
+    const float t = -(AXIS_Z ? n.z * lo.z : rl_dot(n, lo)) / dn;
+    *t_out = t;
+    return (dn != 0.0f) & (t > 0.0f);
+}
 // geometry.rs:123-127
 RL_HD bool rl_inside(RlF3 n, RlF3 off, RlF3 p) { return rl_dot(rl_sub(p, off), n) < 0.0f; }
 
@@ -292,8 +304,10 @@ RL_HD float rl_paraboloid_roots(float a, float b, float c) { // geometry.rs:316-
 // n.d enters squared (a) and through 2 n.d n.o - 2 d.f, whose sign matters only where it and the discriminant's root are both zero --
 // then np = -b + 0 is +0 for either sign of b, never < 0, and nq = +-0 is not < 0 either: no hit both ways; a plane with
 // n.d = +-0 is rejected by `dn != 0`, and with n.lo = +-0 its t = -+0 fails `t > 0` both ways.
+// hit_out (device): where given, *hit_out says whether the returned distance is a hit, and a miss may return any number -- the
+// caller then needs no `!(t < 0)` of its own (the straight-line block of rl_scan_wave).
 template <bool AXIS_Z = false>
-RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir) {
+RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, RlF3 dir, bool* hit_out = nullptr) {
     const RlF3 origin = rl_sub(o, offset);
     const RlF3 focal_offset = rl_sub(origin, focal_point);
     const float n_dot_d = AXIS_Z ? normal.z * dir.z : rl_dot(normal, dir);
@@ -318,14 +332,30 @@ RL_HD float rl_paraboloid_t(RlF3 offset, RlF3 normal, RlF3 focal_point, RlF3 o, 
     // "no hit" here too: every comparison with it is false in both.  The conditions are combined with | and &, not || and &&:
     // as written with those the compiler built a tree of a dozen exec-mask branches around eight compares, ~45 scalar
     // instructions per paraboloid, and a wave's time goes into issuing instructions whatever their kind)
+    // Round 6: the same guarantee from ONE compare.  If max(|b|, sq) >= 2^-90, each numerator is zero or at least 2^-114: a sum of
+    // two floats is a multiple of the smaller one's ulp, so a non-zero -b +- sq is either dominated by the larger operand (>= 2^-91)
+    // or a cancellation between two operands that are both >= 2^-91, i.e. a multiple of 2^-114.  (A NaN among them fails the fast
+    // path's `pick < 0` as it fails every compare of the literal form: no hit both ways.)
+#ifndef RL_PARAB_CHECK_OLD
+    float largest; // max(|b|, sq) -- spelled out: fmaxf comes with a canonicalising v_max_f32 x, x in front (see rl_hex_prism_fast)
+    asm("v_max_f32 %0, |%1|, %2" : "=v"(largest) : "v"(b), "v"(sq));
+    const bool plain = (a < 0.0f) & ((disc < 0.0f) | (largest >= 8.0779356694631609e-28f)); // 2^-90
+#else
     const uint32_t up = (rl_f2u(np) & 0x7fffffffu) - 1u, uq = (rl_f2u(nq) & 0x7fffffffu) - 1u;
     const bool plain = (a < 0.0f) & ((disc < 0.0f) | ((up >= 0x02000000u - 1u) & (uq >= 0x02000000u - 1u)));
+#endif
     if (RL_LIKELY(__builtin_amdgcn_ballot_w64(!plain) == 0)) {
         const float t = 0.5f * pick / a; // (for every lane: the quotient of a miss is discarded -- no branch around the division)
+        if (hit_out) {
+            *hit_out = !(disc < 0.0f) & (pick < 0.0f); // (then t = (pick / 2) / a with both negative: not below zero)
+            return t;
+        }
         return ((disc < 0.0f) | !(pick < 0.0f)) ? -1.0f : t;
     }
 #endif
-    return rl_paraboloid_roots(a, b, c);
+    const float t_literal = rl_paraboloid_roots(a, b, c);
+    if (hit_out) *hit_out = !(t_literal < 0.0f);
+    return t_literal;
 }
 
 // One candidate of a Compound: distance and which half-space.  Inside rl_hex_prism "None" is
@@ -517,6 +547,7 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pr
 #define RL_W_P 1 // rl_hex_prism_fast on the device: the next plane's records in flight behind this plane's arithmetic (A/B builds set 0)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
+    float pair_in = 0.0f, pair_out = 0.0f, pair_dn = 0.0f, pair_ta = 0.0f; // the even plane of the current pair (below)
     RlF4 rec_n, rec_off;
     if (PIPELINED && RL_W_P) {
         if (PRELOADED) rec_n = pre_n, rec_off = pre_off;
@@ -557,10 +588,25 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pr
         dn[k] = dnk;
         ta[k] = tk;
         const bool entering = dnk < 0.0f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // The four running extrema two planes at a time, with v_max3 / v_min3 spelled out (round 6): tk is made by bit operations, so
+        // the compiler cannot rule out a signalling NaN and put a canonicalising v_max_f32 x, x in front of every fmaxf / fminf of
+        // it -- fourteen instructions per round.  The instructions themselves treat a (quiet) NaN as fmaxf / fminf do: the other operand.
+        const float sel_in = entering ? tk : -INF, sel_out = entering ? INF : tk;
+        if (k & 1) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(t_in) : "v"(pair_in), "v"(sel_in));
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(t_out) : "v"(pair_out), "v"(sel_out));
+            asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(min_dn) : "v"(pair_dn), "v"(dnk));
+            asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(min_ta) : "v"(pair_ta), "v"(tk));
+        } else {
+            pair_in = sel_in, pair_out = sel_out, pair_dn = dnk, pair_ta = tk;
+        }
+#else
         t_in = fmaxf(t_in, entering ? tk : -INF);
         t_out = fminf(t_out, entering ? INF : tk);
         min_dn = fminf(min_dn, fabsf(dnk));
         min_ta = fminf(min_ta, fabsf(tk));
+#endif
         const uint32_t tb = rl_f2u(tk);
         min_pos = tb < min_pos ? tb : min_pos;
     }
@@ -593,14 +639,27 @@ RL_HD int rl_hex_prism_fast(const RlF4* pr, RlF3 o, RlF3 d, RlCand* out, RlF4 pr
 #pragma unroll
 #endif
     for (int j = 0; j < 8; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        float larger; // fmaxf(dn[j], dn_in) without the canonicalising v_max_f32 x, x the compiler puts in front (above)
+        asm("v_max_f32 %0, %1, %2" : "=v"(larger) : "v"(dn[j]), "v"(dn_in));
+        const float a = larger * (ta[j] - t_star);
+#else
         const float a = fmaxf(dn[j], dn_in) * (ta[j] - t_star);
+#endif
         margin = fminf(margin, ta[j] == t_star ? INF : a);
     }
     const bool hit_sure = margin > scale * (s0 + d1 * t_star);
     // miss
     const float gap = t0 - t_out;
     const float t_first = (min_pos & 0x80000000u) ? INF : rl_u2f(min_pos);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float least_dn, reach; // fminf(|dn_e|, dn_x), fmaxf(t0, |t_out|): spelled out for the same reason as the extrema above
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(least_dn) : "v"(dn_e), "v"(dn_x));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(reach) : "v"(t0), "v"(t_out));
+    const float miss_a = gap * least_dn, delta_a = 2.0f * scale * (s0 + d1 * reach);
+#else
     const float miss_a = gap * fminf(fabsf(dn_e), dn_x), delta_a = 2.0f * scale * (s0 + d1 * fmaxf(t0, fabsf(t_out)));
+#endif
     const float miss_b = dn_x * (t_first - t_out), delta_b = scale * (s0 + d1 * t_first);
     const bool miss_sure = from_outside ? miss_a > delta_a : (!(t_first < INF) | (miss_b > delta_b));
     sure = sure & (reaches ? hit_sure : miss_sure);
@@ -740,8 +799,10 @@ RL_HD RlIsect rl_finish_hit(const RlSceneView& sv, RlF3 o, RlF3 dir, const RlHit
         const RlF3 rec = rl_xyz(rec4);
         RlF3 curved = rl_sub(is.position, rec); // sphere: position - centre; paraboloid: local_pos
         if (surface_kind == RL_SURFACE_PARABOLOID) {
-            const RlF3 normal = rl_xyz(sv.records[group_index + 1u]);
-            const RlF3 focal_point = rl_xyz(sv.records[group_index + 2u]);
+            const RlF4 rec_n = sv.records[group_index + 1u], rec_f = sv.records[group_index + 2u];
+            asm volatile("" : : "v"(rec_n.w), "v"(rec_f.w)); // (16-byte loads, as above)
+            const RlF3 normal = rl_xyz(rec_n);
+            const RlF3 focal_point = rl_xyz(rec_f);
             const RlF3 plane_pr = rl_sub(curved, rl_mul(normal, rl_dot(curved, normal)));
             curved = rl_sub(focal_point, plane_pr);
         }

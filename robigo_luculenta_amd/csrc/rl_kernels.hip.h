@@ -606,15 +606,15 @@ __device__ __forceinline__ RlHit rl_scan_wave(const RlSceneView& sv, const RlF4*
             // basic blocks, never moves a load up by itself; the fences keep the loads where they are written.)
             auto parab = [&](const RlF4& r0, const RlF4& r1, const RlF4& r2) {
                 if (HOIST_S && SPLIT) asm volatile("" : : "v"(r1.w), "v"(r2.w)); /* 16-byte LDS loads */
-                const float t = rl_paraboloid_t<AXZ>(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir);
-                const bool nearer = !(t < 0.0f) & (t < best.t);
+                bool hit;
+                const float t = rl_paraboloid_t<AXZ>(rl_xyz(r0), rl_xyz(r1), rl_xyz(r2), o, dir, &hit);
+                const bool nearer = hit & (t < best.t);
                 best.t = nearer ? t : best.t;
                 best.obj = nearer ? rl_f2u(r0.w) : best.obj;
             };
             auto plane = [&](const RlF4& r0, const RlF4& r1) {
-                float dn;
-                const float t = rl_plane_t<AXZ>(rl_xyz(r0), rl_xyz(r1), o, dir, &dn);
-                bool hit = t > 0.0f;
+                float t;
+                bool hit = rl_plane_hit<AXZ>(rl_xyz(r0), rl_xyz(r1), o, dir, &t);
                 if (hit && r0.w >= 0.0f) {
                     const RlF3 dp = rl_sub(rl_add(o, rl_mul(dir, t)), rl_xyz(r1));
                     hit = rl_dot(dp, dp) <= r0.w;

@@ -126,6 +126,15 @@ def axis_z_check(seed, n):
     return tuple(int(x) for x in c)
 
 
+def parab_check(seed, n):
+    """The paraboloid's one-division form against the reference's selection: (cases, admitted, hits, disagreements, rejected tiny numerators)."""
+    L = lib()
+    L.mirror_parab_check.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p]
+    c = np.zeros(5, np.uint64)
+    L.mirror_parab_check(seed, n, O.ptr(c))
+    return tuple(int(x) for x in c)
+
+
 def cull_counts(scene, w, h, seed, stream, first, n):
     """What the kernel's sphere pass does with `scene`'s cull table on the segments of paths [first, first + n), counted on
     the host: per segment the (group, ray), (cluster, ray) and (member, ray) pairs that pass, and the table's shape."""

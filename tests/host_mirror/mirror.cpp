@@ -235,6 +235,58 @@ extern "C" void mirror_axis_z_check(uint64_t seed, uint64_t n, uint64_t* counts)
     }
 }
 
+// The paraboloid's one-division form (rl_paraboloid_t, device) against the reference's two-quotient selection (rl_paraboloid_roots) for
+// coefficients over the whole exponent range, under the round-6 condition "a < 0 and (disc < 0 or max(|b|, sqrt|disc|) >= 2^-90)":
+// wherever the condition holds the two must agree (no hit, or the same float).  The device evaluates the identical expressions (its
+// short square root is the IEEE one, tests/test_gpu_parity.py).  counts[0] = cases, [1] = cases the condition admits, [2] = of those:
+// hits, [3] = disagreements (must be 0), [4] = cases with a numerator below 2^-100 that the condition rejects (the reason it exists).
+extern "C" void mirror_parab_check(uint64_t seed, uint64_t n, uint64_t* counts) {
+    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    uint64_t s = seed;
+    auto next = [&]() {
+        s += 0x9e3779b97f4a7c15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    auto wide = [&](int lo, int hi) { // a float with a random sign, a random 24-bit mantissa and an exponent in [lo, hi]
+        const float m = 1.0f + (float)(next() >> 41) * (1.0f / 8388608.0f);
+        const int e = lo + (int)(next() % (uint64_t)(hi - lo + 1));
+        const float v = std::ldexp(m, e);
+        return (next() & 1) ? v : -v;
+    };
+    for (uint64_t i = 0; i < n; ++i) {
+        float a = -std::fabs(wide(-30, 4)), b, c;
+        const uint64_t k = next() % 8;
+        if (k == 0) { b = wide(-149, -80); c = wide(-149, -60) * ((next() & 1) ? 1.0f : 0.0f); }       // tiny b, tiny or zero c
+        else if (k == 1) { b = wide(-20, 20); c = 0.0f; }                                               // a ray that starts on the paraboloid
+        else if (k == 2) { b = wide(-20, 20); c = b * b / (4.0f * a); }                                 // a (nearly) zero discriminant
+        else if (k == 3) { b = 0.0f; c = wide(-149, 20); }
+        else { b = wide(-120, 20); c = wide(-120, 20); }
+        counts[0] += 1;
+        const float disc = b * b - 4.0f * a * c;
+        const float sq = std::sqrt(std::fabs(disc));
+        const float np = -b + sq, nq = -b - sq;
+        const bool admitted = (a < 0.0f) && ((disc < 0.0f) || (std::fmax(std::fabs(b), sq) >= 8.0779356694631609e-28f));
+        if (!admitted) {
+            if ((np != 0.0f && std::fabs(np) < 7.9e-31f) || (nq != 0.0f && std::fabs(nq) < 7.9e-31f)) counts[4] += 1;
+            continue;
+        }
+        counts[1] += 1;
+        const float pick = np < 0.0f ? np : nq;
+        const float t_fast = 0.5f * pick / a;
+        const bool hit_fast = !(disc < 0.0f) && (pick < 0.0f);
+        const float t_ref = rl_paraboloid_roots(a, b, c);
+        const bool hit_ref = !(t_ref < 0.0f);
+        if (hit_fast != hit_ref) counts[3] += 1;
+        else if (hit_ref) {
+            counts[2] += 1;
+            if (rl_f2u(t_fast) != rl_f2u(t_ref)) counts[3] += 1;
+        }
+    }
+}
+
 // ---- rl_hex_prism_fast against the tree it replaces -----------------------------------------------------------------
 // Random and adversarial (prism, ray) pairs over the prisms of `scene`: rays from anywhere, rays that start on a face
 // (as after a refraction: origin = surface point + direction * 1e-5), rays aimed at edges and vertices, rays nearly

@@ -226,6 +226,16 @@ def test_normals_along_z_take_one_product_and_change_no_result():
     assert cases == 4_000_000 and differences == 0 and hits > 400_000 and zeros > 300_000, (cases, hits, differences, zeros)
 
 
+def test_paraboloid_one_division_form_agrees_wherever_its_condition_admits_it():
+    """rl_paraboloid_t on the device divides ONE numerator, chosen by sign, where `a < 0 and (disc < 0 or max(|b|, sqrt|disc|) >= 2^-90)`
+    (round 6: one compare instead of a range check per numerator; the argument is in rl_core.h).  3 M coefficient triples over the whole
+    exponent range, a third of them adversarial (tiny b and c, rays that start on the surface, zero discriminants): wherever the
+    condition holds, the reference's two-quotient selection (geometry.rs:316-341) gives the same answer bit for bit."""
+    cases, admitted, hits, disagreements, rejected_tiny = M.parab_check(6, 3_000_000)
+    assert cases == 3_000_000 and disagreements == 0, (cases, admitted, hits, disagreements)
+    assert admitted > 2_000_000 and hits > 500_000 and rejected_tiny > 1_000, (admitted, hits, rejected_tiny)
+
+
 def test_the_cull_table_is_planned_per_scene():
     """rl_flatten_scene builds the table for each cluster size the kernel has an unrolled member loop for x 3 / 4 clusters per
     group and keeps the plan its cost estimate likes best (rl_scene.cpp: plan_cost over the rays of sample paths).  The
