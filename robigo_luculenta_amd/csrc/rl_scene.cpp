@@ -660,6 +660,13 @@ std::vector<uint32_t> order_by_groups(const std::vector<RlF4>& bounds, std::vect
 #ifndef RL_SUPER_G_DEFAULT
 #define RL_SUPER_G_DEFAULT 8   // cluster groups per super
 #endif
+// From how many cluster groups on a table gets its third level, and how many groups a super bound covers (environment: measurement runs).
+void super_params(uint32_t* min_groups, uint32_t* sg) {
+    *min_groups = RL_SUPER_MIN_GROUPS;
+    *sg = RL_SUPER_G_DEFAULT;
+    if (const char* e = std::getenv("RL_SUPER_MIN")) *min_groups = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RL_SUPER_G")) *sg = (uint32_t)std::min(64, std::max(2, std::atoi(e)));
+}
 struct ClusterPlan {
     uint32_t k, group_gc;
     std::vector<std::vector<uint32_t>> clusters; // in table order, short groups filled with empty clusters
@@ -765,16 +772,41 @@ double plan_cost(const ClusterPlan& plan, const std::vector<RlF4>& rays) {
         return px * px + py * py + pz * pz <= (double)b.w;
     };
     const double n_rays = (double)(rays.size() / 2);
-    double group_pairs = 0, cluster_pairs = 0;
+    // Round 6: a plan with enough groups gets the third level (rl_flatten_scene, the same rule and the same partition): its rays then
+    // test the SUPER bounds wave-uniformly and a super's groups only where the super is reached -- a ring-T round per 64
+    // (super, ray) pairs, in the units below 2.3 + 0.9 per group: calibrated on two measurements (tools/spill_ab.py with RL_SUPER_MIN:
+    // 88 groups in 11 supers cost 3 % more than the 88 wave-uniform tests, 136 groups in 17 supers 10 % less).  Without this the estimate charged every ray for
+    // every group of a large scene, and scenes of 7-8 k objects got clusters of 14 where 10 run 7-9 % faster (tools/spill_ab.py, RL_PLAN).
+    uint32_t min_groups, sg;
+    super_params(&min_groups, &sg);
+    const size_t n_groups = plan.group_bounds.size();
+    std::vector<std::vector<uint32_t>> supers;
+    std::vector<RlF4> super_bounds;
+    if (n_groups >= min_groups && n_groups > sg) {
+        order_by_groups(plan.group_bounds, &supers, sg);
+        for (const std::vector<uint32_t>& members : supers) super_bounds.push_back(group_bound(plan.group_bounds, members));
+    } else {
+        supers.assign(1, std::vector<uint32_t>()); // one pseudo-super that holds every group and is always "reached"
+        for (uint32_t g = 0; g < n_groups; ++g) supers[0].push_back(g);
+    }
+    double super_pairs = 0, group_pairs = 0, cluster_pairs = 0;
     for (size_t r = 0; r + 1 < rays.size(); r += 2) {
-        for (size_t g = 0; g < plan.group_bounds.size(); ++g) {
-            if (!reaches(plan.group_bounds[g], rays[r], rays[r + 1])) continue;
-            group_pairs += 1;
-            for (size_t k = plan.group_gc * g; k < plan.group_gc * (g + 1); ++k)
-                if (reaches(plan.cluster_bounds[k], rays[r], rays[r + 1])) cluster_pairs += 1;
+        for (size_t s = 0; s < supers.size(); ++s) {
+            if (!super_bounds.empty()) {
+                if (!reaches(super_bounds[s], rays[r], rays[r + 1])) continue;
+                super_pairs += 1;
+            }
+            for (uint32_t g : supers[s]) {
+                if (!reaches(plan.group_bounds[g], rays[r], rays[r + 1])) continue;
+                group_pairs += 1;
+                for (size_t k = plan.group_gc * g; k < plan.group_gc * (g + 1); ++k)
+                    if (reaches(plan.cluster_bounds[k], rays[r], rays[r + 1])) cluster_pairs += 1;
+            }
         }
     }
-    const double cost = 0.59 * (double)plan.group_bounds.size() + group_pairs / n_rays * (2.13 + 0.83 * ((double)plan.group_gc - 3.0)) +
+    const double top = super_bounds.empty() ? 0.59 * (double)n_groups
+                                            : 0.59 * (double)super_bounds.size() + super_pairs / n_rays * (2.3 + 0.9 * (double)sg);
+    const double cost = top + group_pairs / n_rays * (2.13 + 0.83 * ((double)plan.group_gc - 3.0)) +
                         cluster_pairs / n_rays * (0.25 + 0.40 * plan.k);
 #ifdef RL_PLAN_DEBUG
     std::fprintf(stderr, "plan: %u per cluster, %u per group: %zu groups, %.2f group pairs and %.2f cluster pairs per sample ray, cost %.2f\n", plan.k,
@@ -977,9 +1009,8 @@ int rl_flatten_scene(const RlSceneDesc* desc, RlFlatScene* out, const char** err
     // only the instantiations that stage the tables or nothing carry the third level's code.  (RL_SUPER_MIN / RL_SUPER_G:
     // measurement runs.)  Which table is chosen never changes a result.
     {
-        uint32_t min_groups = RL_SUPER_MIN_GROUPS, sg = RL_SUPER_G_DEFAULT;
-        if (const char* e = std::getenv("RL_SUPER_MIN")) min_groups = (uint32_t)std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("RL_SUPER_G")) sg = (uint32_t)std::min(64, std::max(2, std::atoi(e)));
+        uint32_t min_groups, sg;
+        super_params(&min_groups, &sg);
         const size_t n_groups = plan.clusters.size() / plan.group_gc;
         if (n_groups >= min_groups && n_groups > sg) {
             std::vector<std::vector<uint32_t>> supers;

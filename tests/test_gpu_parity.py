@@ -624,8 +624,8 @@ def test_third_table_level_scenes_bit_exact_in_every_launch_kind(which):
         assert sum(ran[8:16]) == 0                                                    # never the whole-scene variants
         if fetch == R.FETCH_GLOBAL or which == "random-20000":
             assert sum(ran[16:]) == 0 and sum(ran[:8]) == 3                           # nothing staged
-        else:
-            assert sum(ran[16:]) == 3                                                 # the tables staged
+        else:                                                                         # the tables staged -- where they fit beside ring T and,
+            assert sum(ran[16:]) >= 2 and sum(ran[16:]) + sum(ran[:8]) == 3           # in the open launch, the workgroup's job counters
 
 
 def test_degenerate_scenes_and_empty_launches(demo):
