@@ -16,6 +16,6 @@ for fused in (False, True):
         if quick and (depth, threads) in ((1, 1), (4, 4), (64, 4)): continue
         run(fused, depth, threads)
 for fused in (False, True):
-    for depth, threads in ((16, 16), (32, 16)):
+    for depth, threads in ((16, 16), (32, 32), (48, 48)):   # (more workers than this box has cores: the waits sleep, rl_api.hip session_wait)
         run(fused, depth, threads, True)
 print("open launches so far, {calls carried: launches}:", R.batch_histogram())
